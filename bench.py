@@ -1,0 +1,169 @@
+#!/usr/bin/env python3
+"""bench.py -- forward negacyclic NTT throughput at N = 2^16 on MI355X.
+
+    python bench.py --gpus 1 --steps 20 --warmup 5
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 \
+        --master-port P bench.py --gpus N --steps K --warmup W
+
+A "step" is one forward NTT pass (nwt_2d_radix8_forward_inplace semantics,
+reliability_test/ntt_test.cu:95) over one batch of residue polynomials that is already
+resident in HBM.  Default workload = BASELINE.json configs[1]: N = 2^16, a single
+50-bit prime (the reference's prime size, ntt_test.cu:44), batched over --polys
+polynomials so that the 256 CUs are filled.  --limbs L switches to L distinct primes
+per polynomial (configs[2] shape).  Multi-GPU: residue polynomials are independent, so
+every rank transforms its own batch (weak scaling, no collective on the data path).
+
+Prints ONE JSON line on rank 0 (contract in the task statement) with `roofline`
+(algorithmic bytes 16*N per limb-NTT / HIP-event time vs 8 TB/s) and `cpu_baseline`
+(the oracle's C port timed on one host core).
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+LOGN = 16
+N = 1 << LOGN
+HBM_PEAK_GBS = 8000.0  # MI355X_MICROARCH.md: HBM3E 8 TB/s spec
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=50)
+    ap.add_argument("--warmup", type=int, default=10)
+    ap.add_argument("--polys", type=int, default=256, help="residue polynomials per limb in the batch")
+    ap.add_argument("--limbs", type=int, default=1, help="distinct RNS primes per polynomial")
+    ap.add_argument("--bits", type=int, default=50, help="prime size (50 = reference; 61 = integer path)")
+    ap.add_argument("--no-cpu", action="store_true", help="skip the CPU baseline leg")
+    ap.add_argument("--check", action="store_true", help="verify one limb against the oracle before timing")
+    args = ap.parse_args()
+
+    import torch
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world > 1:
+        import torch.distributed as dist
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group(backend="nccl", device_id=torch.device("cuda", local_rank))
+    torch.cuda.set_device(local_rank)
+
+    import ctypes as C
+
+    import numpy as np
+
+    import fhe_reliability_gpu_amd as F
+    from fhe_reliability_gpu_amd._lib import check, lib
+
+    eng = F.Engine(local_rank)
+    qs = F.create_moduli(N, [args.bits] * args.limbs)
+    tables = eng.tables(LOGN, qs)
+    units = args.polys * args.limbs
+
+    # synthetic residue polynomials: uniform in [0, q_l), seeded per rank, resident in HBM
+    g = torch.Generator(device="cuda")
+    g.manual_seed(2025 + rank)
+    data = torch.empty((args.polys, args.limbs, N), dtype=torch.int64, device="cuda")
+    for l, q in enumerate(qs):
+        data[:, l, :] = torch.randint(0, q, (args.polys, N), generator=g, device="cuda", dtype=torch.int64)
+    pristine = data.clone()
+    stream = torch.cuda.current_stream()
+    sptr = C.c_void_p(stream.cuda_stream)
+    dptr = C.c_void_p(data.data_ptr())
+
+    def step():
+        check(lib.fhe_ntt_forward_batch(eng._h, dptr, tables._h, args.polys, args.limbs, 0, sptr))
+
+    if args.check and rank == 0:
+        from oracle import cport as O
+        step()
+        torch.cuda.synchronize()
+        got = data[0, 0].cpu().numpy().view(np.uint64)
+        want = O.nwt_forward(pristine[0, 0].cpu().numpy().view(np.uint64), qs[0], O.root_powers(qs[0], LOGN))
+        assert (got == want).all(), "GPU forward NTT differs from the oracle"
+        data.copy_(pristine)
+
+    def barrier():
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    # The transform is in place; iterating it on its own output is still a full-rate
+    # forward NTT of canonical residues (outputs are in [0, q)), so no reset inside the loop.
+    for _ in range(args.warmup):
+        step()
+    barrier()
+    ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    t0 = time.perf_counter()
+    ev0.record(stream)
+    for _ in range(args.steps):
+        step()
+    ev1.record(stream)
+    barrier()
+    wall = time.perf_counter() - t0
+    dev_ms = ev0.elapsed_time(ev1)
+    if world > 1:
+        tmax = torch.tensor([wall], device="cuda", dtype=torch.float64)
+        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
+        wall = float(tmax.item())
+
+    ntts = units * args.steps * world
+    value = ntts / wall
+    alg_bytes_per_step = 16.0 * N * units                # 16*N bytes per limb-NTT
+    step_ms_dev = dev_ms / args.steps
+    achieved = alg_bytes_per_step / (step_ms_dev * 1e-3) / 1e9
+
+    result = {
+        "metric": "forward negacyclic NTT/s at N=2^16 (limb-polynomials per second)",
+        "value": value,
+        "unit": "NTT/s",
+        "n_gpus": world,
+        "steps": args.steps,
+        "warmup": args.warmup,
+        "ms_per_step": wall / args.steps * 1e3,
+        "higher_is_better": True,
+        "scaling": "weak",
+        "vs_baseline": None,
+        "dtype": "f64" if args.bits <= 50 else "u64",
+        "data": "synthetic",
+        "config": {
+            "workload": f"N=2^16 forward NTT, {args.limbs} x {args.bits}-bit prime(s), batch of {args.polys} residue polynomials per GPU, in place, HBM resident",
+            "log_n": LOGN, "limbs": args.limbs, "polys_per_gpu": args.polys, "prime_bits": args.bits,
+            "parallelism": f"limb-polynomials sharded over {world} GPU(s), no collective",
+        },
+        "roofline": {
+            "bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
+            "traffic": None,
+            "kernel": "two launches per step (column pass + row pass); achieved = 16*N*units bytes / HIP-event time of the step",
+            "ms_per_step_device": step_ms_dev,
+        },
+    }
+
+    if rank == 0 and not args.no_cpu:
+        from oracle import cport as O
+        rp = O.root_powers(qs[0], LOGN)
+        a = pristine[0, 0].cpu().numpy().view(np.uint64)
+        O.nwt_forward(a, qs[0], rp)                      # warm
+        reps, t = 0, time.perf_counter()
+        while time.perf_counter() - t < 10.0:
+            O.nwt_forward(a, qs[0], rp)
+            reps += 1
+        cpu_s = (time.perf_counter() - t) / reps
+        result["cpu_baseline"] = {
+            "value": 1.0 / cpu_s, "unit": "NTT/s", "cores": 1, "kind": "port",
+            "sample": f"{reps} forward NTTs of one N=2^16 limb (oracle/fhe_oracle.c orc_nwt_forward, u128 mulmod, gcc -O3), ~10 s",
+        }
+    if rank == 0:
+        print(json.dumps(result))
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -1,0 +1,325 @@
+// aux_kernels.hip -- HBM-bound helpers around the transforms: coefficient-wise
+// modular products, bit-reversal gather, four-step glue, bit flips, base conversion,
+// Garner CRT and the BSGS Hadamard accumulate.  All integer work, one element (or one
+// coefficient column) per lane, 64-bit coalesced accesses along N.
+#include "ntt_launch.hpp"
+
+namespace fhe {
+
+// (hi:lo) mod q with ratio = floor(2^128/q) = (r1:r0).  Exact quotient estimate:
+// floor(x*ratio/2^128) is floor(x/q) or one less, so one subtraction finishes; a
+// second is kept for robustness.  This is the 128->64 Barrett step Phantom's
+// DModulus carries its const_ratio for (reliability_test/ntt_test.cu:49-53).
+__device__ __forceinline__ u64 barrett128(u64 lo, u64 hi, u64 q, u64 r0, u64 r1)
+{
+    const u64 c = __umul64hi(lo, r0);
+    const u64 t1l = lo * r1, t1h = __umul64hi(lo, r1);
+    const u64 t2l = hi * r0, t2h = __umul64hi(hi, r0);
+    u64 s = t1l + t2l;
+    u64 carry = s < t1l;
+    const u64 s2 = s + c;
+    carry += s2 < s;
+    const u64 qhat = hi * r1 + t1h + t2h + carry;
+    u64 r = lo - qhat * q;
+    r = r >= q ? r - q : r;
+    r = r >= q ? r - q : r;
+    return r;
+}
+__device__ __forceinline__ u64 mulmod_b(u64 a, u64 b, u64 q, u64 r0, u64 r1)
+{
+    return barrett128(a * b, __umul64hi(a, b), q, r0, r1);
+}
+// Shoup product with full correction: exact (a*w mod q) for ANY 64-bit a, w < q
+__device__ __forceinline__ u64 mulmod_shoup(u64 a, u64 w, u64 ws, u64 q)
+{
+    u64 r = a * w - __umul64hi(a, ws) * q;
+    return r >= q ? r - q : r;
+}
+
+// ---------------------------------------------------------------------------
+template <bool ACC>
+__global__ __launch_bounds__(256) void k_modmul(PointwiseArgs p)
+{
+    const u64 n = (u64)1 << p.logn;
+    const u64 total = (u64)p.units << p.logn;
+    for (u64 i_ = (blockIdx.x * (u64)blockDim.x + threadIdx.x) * 2; i_ < total; i_ += (u64)gridDim.x * blockDim.x * 2) {
+        const u32 unit = (u32)(i_ >> p.logn);
+        const u32 poly = unit / p.limbs, l = unit % p.limbs;
+        const LimbParams &lp = p.lp[p.limb0 + l];
+        const u64 q = lp.q, r0 = lp.barrett_lo, r1 = lp.barrett_hi;
+        {
+            const u64 i = (((u64)poly * p.poly_stride + l) << p.logn) + (i_ & (n - 1));
+            const ulonglong2 a = *reinterpret_cast<const ulonglong2 *>(p.a + i);
+            const ulonglong2 b = *reinterpret_cast<const ulonglong2 *>(p.b + i);
+            ulonglong2 c;
+            c.x = mulmod_b(a.x, b.x, q, r0, r1);
+            c.y = mulmod_b(a.y, b.y, q, r0, r1);
+            if (ACC) {
+                const ulonglong2 o = *reinterpret_cast<const ulonglong2 *>(p.c + i);
+                u64 x = c.x + barrett128(o.x, 0, q, r0, r1), y = c.y + barrett128(o.y, 0, q, r0, r1);
+                c.x = x >= q ? x - q : x;
+                c.y = y >= q ? y - q : y;
+            }
+            *reinterpret_cast<ulonglong2 *>(p.c + i) = c;
+        }
+    }
+}
+
+hipError_t launch_modmul(hipStream_t st, const PointwiseArgs &p, bool accumulate)
+{
+    const u64 total = (u64)p.units << p.logn;
+    if (!total) return hipSuccess;
+    u64 want = (total / 2 + 255) / 256;
+    const u32 blocks = (u32)(want < 1 ? 1 : want > 8192 ? 8192 : want);
+    if (accumulate) hipLaunchKernelGGL(k_modmul<true>, dim3(blocks), dim3(256), 0, st, p);
+    else hipLaunchKernelGGL(k_modmul<false>, dim3(blocks), dim3(256), 0, st, p);
+    return hipGetLastError();
+}
+
+// ---------------------------------------------------------------------------
+__global__ void k_flip_bit(u64 *data, u64 idx, int bit) { data[idx] ^= (u64)1 << bit; }
+
+hipError_t launch_flip_bit(hipStream_t st, u64 *data, u64 idx, int bit)
+{
+    hipLaunchKernelGGL(k_flip_bit, dim3(1), dim3(1), 0, st, data, idx, bit);
+    return hipGetLastError();
+}
+
+// ---------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void k_bitrev_scale(u64 *dst, const u64 *src, int logn, u64 total, ModConst mc, u64 sc,
+                                                      bool do_scale)
+{
+    const u64 q = mc.q, r0 = mc.r0, r1 = mc.r1;
+    const u64 mask = ((u64)1 << logn) - 1;
+    for (u64 i = blockIdx.x * (u64)blockDim.x + threadIdx.x; i < total; i += (u64)gridDim.x * blockDim.x) {
+        const u64 lo = i & mask;
+        const u64 j = logn ? (__brevll(lo) >> (64 - logn)) : 0;
+        u64 v = src[(i & ~mask) | j];
+        if (do_scale) v = mulmod_b(v, sc, q, r0, r1);
+        dst[i] = v;
+    }
+}
+
+hipError_t launch_bitrev_scale(hipStream_t st, u64 *dst, const u64 *src, int logn, u32 units, const ModConst &mc, u64 scale,
+                               bool do_scale)
+{
+    const u64 total = (u64)units << logn;
+    if (!total) return hipSuccess;
+    u64 want = (total + 255) / 256;
+    hipLaunchKernelGGL(k_bitrev_scale, dim3((u32)(want > 8192 ? 8192 : want)), dim3(256), 0, st, dst, src, logn, total, mc,
+                       scale, do_scale);
+    return hipGetLastError();
+}
+
+// out[c*rows + r] = in[r*cols + brev(c)] * tw[r*cols + c]
+__global__ __launch_bounds__(256) void k_fourstep_mid(u64 *out, const u64 *in, u32 rows, u32 cols, int log_cols,
+                                                      const u64 *tw, ModConst mc, bool with_twiddle)
+{
+    const u64 q = mc.q, r0 = mc.r0, r1 = mc.r1;
+    const u64 total = (u64)rows * cols;
+    for (u64 o = blockIdx.x * (u64)blockDim.x + threadIdx.x; o < total; o += (u64)gridDim.x * blockDim.x) {
+        const u32 c = (u32)(o / rows), r = (u32)(o % rows);
+        const u32 cb = log_cols ? (__brev(c) >> (32 - log_cols)) : 0;
+        u64 v = in[(u64)r * cols + cb];
+        if (with_twiddle) v = mulmod_b(v, tw[(u64)r * cols + c], q, r0, r1);
+        out[o] = v;
+    }
+}
+
+hipError_t launch_fourstep_mid(hipStream_t st, u64 *out, const u64 *in, u32 rows, u32 cols, int log_cols, const u64 *tw,
+                               const ModConst &mc, bool with_twiddle)
+{
+    const u64 total = (u64)rows * cols;
+    u64 want = (total + 255) / 256;
+    hipLaunchKernelGGL(k_fourstep_mid, dim3((u32)(want > 8192 ? 8192 : want)), dim3(256), 0, st, out, in, rows, cols,
+                       log_cols, tw, mc, with_twiddle);
+    return hipGetLastError();
+}
+
+// out[c][r] = in[r][c], 32x32 tiles through LDS (+1 padding against bank conflicts)
+__global__ __launch_bounds__(256) void k_transpose(u64 *out, const u64 *in, u32 rows, u32 cols)
+{
+    __shared__ u64 tile[32][33];
+    const u32 tx = threadIdx.x & 31, ty = threadIdx.x >> 5; // 32 x 8
+    const u32 tiles_c = (cols + 31) / 32, tiles_r = (rows + 31) / 32;
+    for (u32 t = blockIdx.x; t < tiles_c * tiles_r; t += gridDim.x) {
+        const u32 tr = t / tiles_c, tc = t % tiles_c;
+        for (u32 k = ty; k < 32; k += 8) {
+            const u32 r = tr * 32 + k, c = tc * 32 + tx;
+            if (r < rows && c < cols) tile[k][tx] = in[(u64)r * cols + c];
+        }
+        __syncthreads();
+        for (u32 k = ty; k < 32; k += 8) {
+            const u32 c = tc * 32 + k, r = tr * 32 + tx;
+            if (r < rows && c < cols) out[(u64)c * rows + r] = tile[tx][k];
+        }
+        __syncthreads();
+    }
+}
+
+hipError_t launch_transpose(hipStream_t st, u64 *out, const u64 *in, u32 rows, u32 cols)
+{
+    const u32 tiles = ((cols + 31) / 32) * ((rows + 31) / 32);
+    hipLaunchKernelGGL(k_transpose, dim3(tiles > 8192 ? 8192 : tiles), dim3(256), 0, st, out, in, rows, cols);
+    return hipGetLastError();
+}
+
+// ---------------------------------------------------------------------------
+// Base conversion.  One lane = one coefficient; residues are read at stride N
+// (coalesced across lanes), mixed-radix digits stay in registers.
+// ---------------------------------------------------------------------------
+constexpr int BC_MAX_LIMBS = 64;
+
+// digits of x in the mixed radix (p_0, p_1, ...): x = c_0 + c_1 p_0 + c_2 p_0 p_1 + ...
+template <int MAXM>
+__device__ __forceinline__ void garner_digits(u64 (&c)[MAXM], const u64 *in, u64 N, u64 i, const BaseConvPlanDev &pl)
+{
+    const int m = pl.m;
+    for (int j = 0; j < m && j < MAXM; j++) {
+        const u64 pj = pl.mod_in[j], r0 = pl.ratio_in[2 * j], r1 = pl.ratio_in[2 * j + 1];
+        u64 t = barrett128(in[(u64)j * N + i], 0, pj, r0, r1);
+        // t = (...((r_j - c_0) p_0^-1 - c_1) p_1^-1 ...) mod p_j
+        for (int l = 0; l < j; l++) {
+            const u64 cl = barrett128(c[l], 0, pj, r0, r1);
+            const u64 d = t >= cl ? t - cl : t + pj - cl;
+            t = mulmod_b(d, pl.inv_pl_mod_pj[l * m + j], pj, r0, r1);
+        }
+        c[j] = t;
+    }
+}
+
+template <int MAXM>
+__global__ __launch_bounds__(256) void k_baseconv_exact(u64 *out, const u64 *in, BaseConvPlanDev pl, u64 N)
+{
+    for (u64 i = blockIdx.x * (u64)blockDim.x + threadIdx.x; i < N; i += (u64)gridDim.x * blockDim.x) {
+        u64 c[MAXM];
+        garner_digits<MAXM>(c, in, N, i, pl);
+        // motivation/baseConv.py:79-81: x mod q_o, Horner over the mixed-radix digits
+        for (int o = 0; o < pl.k; o++) {
+            const u64 q = pl.mod_out[o], r0 = pl.ratio_out[2 * o], r1 = pl.ratio_out[2 * o + 1];
+            u64 acc = 0;
+            for (int l = pl.m - 1; l >= 0; l--) {
+                acc = mulmod_b(acc, pl.pl_mod_qo[l * pl.k + o], q, r0, r1);
+                const u64 cl = barrett128(c[l], 0, q, r0, r1);
+                acc += cl;
+                acc = acc >= q ? acc - q : acc;
+            }
+            out[(u64)o * N + i] = acc;
+        }
+    }
+}
+
+hipError_t launch_baseconv_exact(hipStream_t st, u64 *out, const u64 *in, const BaseConvPlanDev &pl, u64 N)
+{
+    if (pl.m > BC_MAX_LIMBS) return hipErrorInvalidValue;
+    u64 want = (N + 255) / 256;
+    const dim3 grid((u32)(want > 4096 ? 4096 : want));
+    if (pl.m <= 8) hipLaunchKernelGGL(k_baseconv_exact<8>, grid, dim3(256), 0, st, out, in, pl, N);
+    else if (pl.m <= 16) hipLaunchKernelGGL(k_baseconv_exact<16>, grid, dim3(256), 0, st, out, in, pl, N);
+    else if (pl.m <= 32) hipLaunchKernelGGL(k_baseconv_exact<32>, grid, dim3(256), 0, st, out, in, pl, N);
+    else hipLaunchKernelGGL(k_baseconv_exact<64>, grid, dim3(256), 0, st, out, in, pl, N);
+    return hipGetLastError();
+}
+
+// rfhe_framewk/src/baseConv.py:10-40: out[o][i] = sum_j ((r_j * Phat_j * inv_j) mod q_o), sum NOT reduced
+__global__ __launch_bounds__(256) void k_bconv_fast(u64 *out, const u64 *in, BaseConvPlanDev pl, u64 N)
+{
+    for (u64 i = blockIdx.x * (u64)blockDim.x + threadIdx.x; i < N; i += (u64)gridDim.x * blockDim.x) {
+        for (int o = 0; o < pl.k; o++) {
+            const u64 q = pl.mod_out[o];
+            u64 total = 0;
+            for (int j = 0; j < pl.m; j++)
+                total += mulmod_shoup(in[(u64)j * N + i], pl.fast_coef[j * pl.k + o], pl.fast_coef_shoup[j * pl.k + o], q);
+            out[(u64)o * N + i] = total;
+        }
+    }
+}
+
+hipError_t launch_bconv_fast(hipStream_t st, u64 *out, const u64 *in, const BaseConvPlanDev &pl, u64 N)
+{
+    u64 want = (N + 255) / 256;
+    hipLaunchKernelGGL(k_bconv_fast, dim3((u32)(want > 4096 ? 4096 : want)), dim3(256), 0, st, out, in, pl, N);
+    return hipGetLastError();
+}
+
+// rfhe_framewk/src/baseConv.cu:85-120 (crt_kernel) re-expressed for gfx950: same
+// Garner recurrence and the same 128-bit wrap-around of c_k * pref_k and of the sum;
+// the 128 % 64 steps use the Barrett ratio instead of a software division.
+constexpr int GARNER_MAX = 16;
+__global__ __launch_bounds__(256) void k_crt_garner(u64 *x_lo, u64 *x_hi, const u64 *res, const u64 *mod, const u64 *ratio,
+                                                    const u64 *pref_lo, const u64 *pref_hi, const u64 *inv_pref, int m, u64 N)
+{
+    for (u64 i = blockIdx.x * (u64)blockDim.x + threadIdx.x; i < N; i += (u64)gridDim.x * blockDim.x) {
+        u64 c[GARNER_MAX];
+        c[0] = res[i];
+        for (int j = 1; j < m; j++) {
+            const u64 pj = mod[j], r0 = ratio[2 * j], r1 = ratio[2 * j + 1];
+            u64 t = barrett128(res[(u64)j * N + i], 0, pj, r0, r1);
+            for (int k = 0; k < j; k++) {
+                // prod = c_k * pref_k wrapped to 128 bits
+                const u64 lo = c[k] * pref_lo[k];
+                const u64 hi = __umul64hi(c[k], pref_lo[k]) + c[k] * pref_hi[k];
+                const u64 r = barrett128(lo, hi, pj, r0, r1);
+                t = t >= r ? t - r : t + pj - r;
+            }
+            c[j] = mulmod_b(t, inv_pref[j], pj, r0, r1);
+        }
+        u64 lo = 0, hi = 0;
+        for (int k = 0; k < m; k++) {
+            const u64 pl = c[k] * pref_lo[k];
+            const u64 ph = __umul64hi(c[k], pref_lo[k]) + c[k] * pref_hi[k];
+            const u64 nl = lo + pl;
+            hi += ph + (nl < lo);
+            lo = nl;
+        }
+        x_lo[i] = lo;
+        x_hi[i] = hi;
+    }
+}
+
+hipError_t launch_crt_garner(hipStream_t st, u64 *x_lo, u64 *x_hi, const u64 *residues, const u64 *moduli, const u64 *ratios,
+                             const u64 *pref_lo, const u64 *pref_hi, const u64 *inv_pref, int m, u64 N)
+{
+    if (m < 1 || m > GARNER_MAX) return hipErrorInvalidValue;
+    u64 want = (N + 255) / 256;
+    hipLaunchKernelGGL(k_crt_garner, dim3((u32)(want > 4096 ? 4096 : want)), dim3(256), 0, st, x_lo, x_hi, residues, moduli,
+                       ratios, pref_lo, pref_hi, inv_pref, m, N);
+    return hipGetLastError();
+}
+
+// motivation/bsgs.py:39-52: y_i = sum_j M[(j - i) mod k] (.) v_j.  lp == nullptr keeps
+// the reference's int64 wrap-around (NumPy, no reduction); otherwise mod q.
+__global__ __launch_bounds__(256) void k_bsgs_hadamard(u64 *y, const u64 *M, const u64 *v, int k, int bs, ModConst mc, bool lp)
+{
+    const u64 total = (u64)k * bs;
+    for (u64 o = blockIdx.x * (u64)blockDim.x + threadIdx.x; o < total; o += (u64)gridDim.x * blockDim.x) {
+        const int i = (int)(o / bs), e = (int)(o % bs);
+        u64 acc = 0;
+        if (lp) {
+            const u64 q = mc.q, r0 = mc.r0, r1 = mc.r1;
+            for (int j = 0; j < k; j++) {
+                int b = j - i;
+                b = b < 0 ? b + k : b;
+                acc += mulmod_b(M[(u64)b * bs + e], v[(u64)j * bs + e], q, r0, r1);
+                acc = acc >= q ? acc - q : acc;
+            }
+        } else {
+            for (int j = 0; j < k; j++) {
+                int b = j - i;
+                b = b < 0 ? b + k : b;
+                acc += M[(u64)b * bs + e] * v[(u64)j * bs + e];
+            }
+        }
+        y[o] = acc;
+    }
+}
+
+hipError_t launch_bsgs_hadamard(hipStream_t st, u64 *y, const u64 *M_blocks, const u64 *v, int k, int bs, const ModConst *mc)
+{
+    u64 want = ((u64)k * bs + 255) / 256;
+    hipLaunchKernelGGL(k_bsgs_hadamard, dim3((u32)(want > 4096 ? 4096 : want)), dim3(256), 0, st, y, M_blocks, v, k, bs,
+                       mc ? *mc : ModConst{1, 0, 0}, mc != nullptr);
+    return hipGetLastError();
+}
+
+} // namespace fhe

@@ -1,0 +1,781 @@
+// capi.cpp -- the C ABI declared in include/fhe_mi355x.h: handle management, table
+// construction and launch sequencing.  No arithmetic on residues happens on the host
+// here; there is no CPU fallback -- every transform call ends in a HIP kernel launch
+// or an error.
+#include "../../include/fhe_mi355x.h"
+
+#include <hip/hip_runtime.h>
+
+#include <cstdio>
+#include <cstring>
+#include <map>
+#include <memory>
+#include <mutex>
+#include <string>
+#include <tuple>
+#include <vector>
+
+#include "host_math.hpp"
+#include "ntt_launch.hpp"
+
+using namespace fhe;
+
+namespace {
+
+thread_local std::string g_err;
+
+int fail(int code, const std::string &msg)
+{
+    g_err = msg;
+    return code;
+}
+int hip_fail(hipError_t e, const char *what)
+{
+    g_err = std::string(what) + ": " + hipGetErrorString(e);
+    return FHE_ERR_HIP;
+}
+#define HIP_TRY(expr)                                          \
+    do {                                                       \
+        hipError_t e_ = (expr);                                \
+        if (e_ != hipSuccess) return hip_fail(e_, #expr);      \
+    } while (0)
+
+struct DevBuf {
+    void *p = nullptr;
+    size_t bytes = 0;
+    ~DevBuf()
+    {
+        if (p) (void)hipFree(p);
+    }
+    hipError_t alloc(size_t n)
+    {
+        if (p) (void)hipFree(p);
+        p = nullptr;
+        bytes = n;
+        return hipMalloc(&p, n ? n : 16);
+    }
+    template <class T> hipError_t upload(const std::vector<T> &v)
+    {
+        hipError_t e = alloc(v.size() * sizeof(T));
+        if (e != hipSuccess) return e;
+        return hipMemcpy(p, v.data(), v.size() * sizeof(T), hipMemcpyHostToDevice);
+    }
+    template <class T> T *as() const { return static_cast<T *>(p); }
+};
+
+} // namespace
+
+struct fhe_ntt_tables {
+    fhe_ctx *ctx = nullptr;
+    int log_n = 0, count = 0;
+    std::vector<u64> q, psi;
+    std::vector<int> path;
+    std::vector<LimbParams> h_lp;
+    DevBuf d_lp, d_tw;
+    bool has_inverse = true;
+};
+
+struct fhe_baseconv {
+    int m = 0, k = 0;
+    bool fast_ok = true;
+    DevBuf mod_in, mod_out, ratio_in, ratio_out, inv_pl_pj, pl_qo, fast_coef, fast_shoup;
+    BaseConvPlanDev dev{};
+};
+
+struct GarnerTables {
+    DevBuf mod, ratio, pref_lo, pref_hi, inv_pref;
+};
+
+struct fhe_ctx {
+    int device = 0;
+    hipStream_t stream = nullptr;
+    std::mutex mu;
+    // cyclic tables keyed by (log_n, mod, root, convention)
+    std::map<std::tuple<int, u64, u64, int>, std::unique_ptr<fhe_ntt_tables>> cyclic;
+    std::map<std::vector<u64>, std::unique_ptr<GarnerTables>> garner;
+};
+
+struct fhe_fourstep {
+    fhe_ctx *ctx = nullptr;
+    u64 n1 = 0, n2 = 0, mod = 0;
+    int log1 = 0, log2 = 0;
+    fhe_ntt_tables *t1 = nullptr, *t2 = nullptr; // sub-transform tables of length n1 / n2
+    DevBuf tw, buf0, buf1;
+    ModConst mc{};
+};
+
+namespace {
+
+hipStream_t pick(fhe_ctx *ctx, void *stream) { return stream ? static_cast<hipStream_t>(stream) : ctx->stream; }
+
+int path_for(u64 q)
+{
+    if (q < 2) return -1;
+    if (q < ((u64)1 << 50)) return PATH_F64;
+    if (q < ((u64)1 << 61)) return PATH_U64;
+    return -1;
+}
+
+Tw encode(int path, u64 w, u64 q) { return path == PATH_F64 ? ArithF64::encode(w, q) : ArithU64::encode(w, q); }
+
+// entry-wise inverses of t[1..n-1] mod q by Montgomery's batch trick; false when an
+// entry is not a unit
+bool batch_inverse(const u64 *t, size_t n, u64 q, std::vector<u64> &out)
+{
+    out.assign(n, 0);
+    if (n < 2) return true;
+    std::vector<u64> pre(n);
+    u64 acc = 1 % q;
+    for (size_t i = 1; i < n; i++) {
+        pre[i] = acc;
+        acc = host::mul_mod(acc, t[i] % q, q);
+    }
+    u64 inv = host::inv_mod(acc, q);
+    if (!inv && q != 1) return false;
+    for (size_t i = n - 1; i >= 1; i--) {
+        out[i] = host::mul_mod(inv, pre[i], q);
+        inv = host::mul_mod(inv, t[i] % q, q);
+    }
+    return true;
+}
+
+// Build device tables from forward tables in canonical residues (count x N).
+int build_tables(fhe_ctx *ctx, int log_n, const u64 *q, int count, const u64 *fwd_rows, bool want_inverse, int force_path,
+                 const u64 *psi_or_null, fhe_ntt_tables **out)
+{
+    if (!ctx || !q || !out || count < 1 || log_n < 1 || log_n > NTT_MAX_LOGN) return fail(FHE_ERR_INVALID, "bad table arguments");
+    const size_t N = (size_t)1 << log_n;
+    std::unique_ptr<fhe_ntt_tables> t(new fhe_ntt_tables);
+    t->ctx = ctx;
+    t->log_n = log_n;
+    t->count = count;
+    t->q.assign(q, q + count);
+    t->psi.assign(count, 0);
+    t->path.resize(count);
+    t->h_lp.resize(count);
+    t->has_inverse = want_inverse;
+    std::vector<Tw> tw((size_t)count * 2 * N);
+    HIP_TRY(hipSetDevice(ctx->device));
+    HIP_TRY(t->d_tw.alloc(tw.size() * sizeof(Tw)));
+    std::vector<u64> inv;
+    for (int l = 0; l < count; l++) {
+        const int path = force_path >= 0 ? force_path : path_for(q[l]);
+        if (path < 0 || (path == PATH_F64 && q[l] >= ((u64)1 << 50)) || q[l] >= ((u64)1 << 61) || q[l] < 2)
+            return fail(FHE_ERR_UNSUPPORTED, "modulus must satisfy 2 <= q < 2^61 (FP64 path: q < 2^50)");
+        t->path[l] = path;
+        const u64 *row = fwd_rows + (size_t)l * N;
+        Tw *f = tw.data() + (size_t)l * 2 * N, *b = f + N;
+        for (size_t k = 0; k < N; k++) f[k] = encode(path, row[k] % q[l], q[l]);
+        bool inv_ok = false;
+        if (want_inverse) inv_ok = batch_inverse(row, N, q[l], inv);
+        if (inv_ok) {
+            inv[0] = 1 % q[l];
+            for (size_t k = 0; k < N; k++) b[k] = encode(path, inv[k], q[l]);
+        } else {
+            for (size_t k = 0; k < N; k++) b[k] = f[k];
+            t->has_inverse = false;
+        }
+        LimbParams &p = t->h_lp[l];
+        std::memset(&p, 0, sizeof p);
+        p.q = q[l];
+        p.two_q = 2 * q[l];
+        p.n = (double)q[l];
+        p.ninv = 1.0 / p.n;
+        const u64 ninv = host::inv_mod((u64)(N % q[l]), q[l]);
+        if (!ninv && want_inverse) t->has_inverse = false;
+        p.inv_n = encode(path, ninv, q[l]);
+        p.fwd = t->d_tw.as<Tw>() + (size_t)l * 2 * N;
+        p.inv = p.fwd + N;
+        u64 cr[3];
+        host::const_ratio(q[l], cr);
+        p.barrett_lo = cr[0];
+        p.barrett_hi = cr[1];
+        p.path = path;
+        if (psi_or_null) t->psi[l] = psi_or_null[l];
+    }
+    HIP_TRY(hipMemcpy(t->d_tw.p, tw.data(), tw.size() * sizeof(Tw), hipMemcpyHostToDevice));
+    HIP_TRY(t->d_lp.upload(t->h_lp));
+    *out = t.release();
+    return FHE_OK;
+}
+
+// one launch per maximal run of limbs that share an arithmetic path
+template <class F> int for_each_run(const fhe_ntt_tables *t, size_t limbs, size_t start_idx, F f)
+{
+    size_t i = 0;
+    while (i < limbs) {
+        size_t j = i + 1;
+        while (j < limbs && t->path[start_idx + j] == t->path[start_idx + i]) j++;
+        int rc = f(i, j - i, t->path[start_idx + i]);
+        if (rc != FHE_OK) return rc;
+        i = j;
+    }
+    return FHE_OK;
+}
+
+int check_range(const fhe_ntt_tables *t, size_t n_poly, size_t limbs, size_t start_idx)
+{
+    if (!t) return fail(FHE_ERR_INVALID, "null tables");
+    if (start_idx + limbs > (size_t)t->count) return fail(FHE_ERR_INVALID, "limb range exceeds the table set");
+    if (n_poly * limbs > ((size_t)1 << 24)) return fail(FHE_ERR_INVALID, "batch too large for one launch (max 2^24 limb-polynomials)");
+    return FHE_OK;
+}
+
+int ntt_batch(fhe_ctx *ctx, u64 *d, const fhe_ntt_tables *t, size_t n_poly, size_t limbs, size_t start_idx, void *stream,
+              bool inverse)
+{
+    if (!ctx || !d) return fail(FHE_ERR_INVALID, "null argument");
+    int rc = check_range(t, n_poly, limbs, start_idx);
+    if (rc) return rc;
+    if (inverse && !t->has_inverse) return fail(FHE_ERR_UNSUPPORTED, "table set has no inverse (twiddle or N not invertible)");
+    if (!n_poly || !limbs) return FHE_OK;
+    HIP_TRY(hipSetDevice(ctx->device));
+    hipStream_t st = pick(ctx, stream);
+    const size_t N = (size_t)1 << t->log_n;
+    return for_each_run(t, limbs, start_idx, [&](size_t off, size_t len, int path) -> int {
+        PassArgs a{d + off * N, t->d_lp.as<LimbParams>(), (u32)(start_idx + off), (u32)len, (u32)(n_poly * len), (u32)limbs};
+        hipError_t e = launch_ntt(st, a, t->log_n, inverse, path);
+        if (e != hipSuccess) return hip_fail(e, "launch_ntt");
+        return FHE_OK;
+    });
+}
+
+int pointwise(fhe_ctx *ctx, u64 *c, const u64 *a, const u64 *b, const fhe_ntt_tables *t, size_t n_poly, size_t limbs,
+              size_t start_idx, void *stream, bool acc)
+{
+    if (!ctx || !c || !a || !b) return fail(FHE_ERR_INVALID, "null argument");
+    int rc = check_range(t, n_poly, limbs, start_idx);
+    if (rc) return rc;
+    HIP_TRY(hipSetDevice(ctx->device));
+    PointwiseArgs p{c, a, b, t->d_lp.as<LimbParams>(), (u32)start_idx, (u32)limbs, (u32)(n_poly * limbs), (u32)limbs, t->log_n};
+    hipError_t e = launch_modmul(pick(ctx, stream), p, acc);
+    if (e != hipSuccess) return hip_fail(e, "launch_modmul");
+    return FHE_OK;
+}
+
+ModConst mod_const(u64 q)
+{
+    u64 cr[3];
+    host::const_ratio(q, cr);
+    return ModConst{q, cr[0], cr[1]};
+}
+
+int ilog2_exact(u64 v)
+{
+    if (!v || (v & (v - 1))) return -1;
+    return 63 - __builtin_clzll(v);
+}
+
+} // namespace
+
+extern "C" {
+
+int fhe_version(void) { return 100; }
+const char *fhe_last_error(void) { return g_err.c_str(); }
+
+int fhe_ctx_create(int device, fhe_ctx **out)
+{
+    if (!out) return fail(FHE_ERR_INVALID, "null out");
+    int n = 0;
+    HIP_TRY(hipGetDeviceCount(&n));
+    if (device < 0 || device >= n) return fail(FHE_ERR_INVALID, "no such HIP device");
+    HIP_TRY(hipSetDevice(device));
+    std::unique_ptr<fhe_ctx> c(new fhe_ctx);
+    c->device = device;
+    HIP_TRY(hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking));
+    *out = c.release();
+    return FHE_OK;
+}
+
+int fhe_ctx_destroy(fhe_ctx *ctx)
+{
+    if (!ctx) return FHE_OK;
+    (void)hipSetDevice(ctx->device);
+    (void)hipStreamSynchronize(ctx->stream);
+    ctx->cyclic.clear();
+    ctx->garner.clear();
+    (void)hipStreamDestroy(ctx->stream);
+    delete ctx;
+    return FHE_OK;
+}
+
+int fhe_ctx_stream(fhe_ctx *ctx, void **stream_out)
+{
+    if (!ctx || !stream_out) return fail(FHE_ERR_INVALID, "null argument");
+    *stream_out = ctx->stream;
+    return FHE_OK;
+}
+
+int fhe_sync(fhe_ctx *ctx, void *stream)
+{
+    if (!ctx) return fail(FHE_ERR_INVALID, "null ctx");
+    HIP_TRY(hipSetDevice(ctx->device));
+    HIP_TRY(hipStreamSynchronize(pick(ctx, stream)));
+    return FHE_OK;
+}
+
+int fhe_alloc(fhe_ctx *ctx, size_t bytes, void **dptr)
+{
+    if (!ctx || !dptr) return fail(FHE_ERR_INVALID, "null argument");
+    HIP_TRY(hipSetDevice(ctx->device));
+    hipError_t e = hipMalloc(dptr, bytes ? bytes : 16);
+    if (e == hipErrorOutOfMemory) return fail(FHE_ERR_NOMEM, "hipMalloc: out of device memory");
+    if (e != hipSuccess) return hip_fail(e, "hipMalloc");
+    return FHE_OK;
+}
+
+int fhe_free(fhe_ctx *ctx, void *dptr)
+{
+    if (!ctx) return fail(FHE_ERR_INVALID, "null ctx");
+    if (!dptr) return FHE_OK;
+    HIP_TRY(hipSetDevice(ctx->device));
+    HIP_TRY(hipFree(dptr));
+    return FHE_OK;
+}
+
+int fhe_h2d(fhe_ctx *ctx, void *dst, const void *src, size_t bytes, void *stream)
+{
+    if (!ctx || (!dst && bytes) || (!src && bytes)) return fail(FHE_ERR_INVALID, "null argument");
+    HIP_TRY(hipSetDevice(ctx->device));
+    HIP_TRY(hipMemcpyAsync(dst, src, bytes, hipMemcpyHostToDevice, pick(ctx, stream)));
+    return FHE_OK;
+}
+int fhe_d2h(fhe_ctx *ctx, void *dst, const void *src, size_t bytes, void *stream)
+{
+    if (!ctx || (!dst && bytes) || (!src && bytes)) return fail(FHE_ERR_INVALID, "null argument");
+    HIP_TRY(hipSetDevice(ctx->device));
+    HIP_TRY(hipMemcpyAsync(dst, src, bytes, hipMemcpyDeviceToHost, pick(ctx, stream)));
+    return FHE_OK;
+}
+int fhe_d2d(fhe_ctx *ctx, void *dst, const void *src, size_t bytes, void *stream)
+{
+    if (!ctx || (!dst && bytes) || (!src && bytes)) return fail(FHE_ERR_INVALID, "null argument");
+    HIP_TRY(hipSetDevice(ctx->device));
+    HIP_TRY(hipMemcpyAsync(dst, src, bytes, hipMemcpyDeviceToDevice, pick(ctx, stream)));
+    return FHE_OK;
+}
+int fhe_memset(fhe_ctx *ctx, void *dst, int byte, size_t bytes, void *stream)
+{
+    if (!ctx || (!dst && bytes)) return fail(FHE_ERR_INVALID, "null argument");
+    HIP_TRY(hipSetDevice(ctx->device));
+    HIP_TRY(hipMemsetAsync(dst, byte, bytes, pick(ctx, stream)));
+    return FHE_OK;
+}
+
+// ---------------------------------------------------------------- host tables
+int fhe_moduli_create(uint64_t N, const int *bits, int count, uint64_t *out_q)
+{
+    if (!bits || !out_q || count < 1 || N < 1 || (N & (N - 1))) return fail(FHE_ERR_INVALID, "bad arguments");
+    for (int i = 0; i < count; i++)
+        if (bits[i] < 2 || bits[i] > 61) return fail(FHE_ERR_UNSUPPORTED, "bit sizes must be in [2, 61]");
+    if (!host::create_moduli(N, bits, count, out_q)) return fail(FHE_ERR_INVALID, "not enough primes of the requested size");
+    return FHE_OK;
+}
+
+int fhe_modulus_const_ratio(uint64_t q, uint64_t out[3])
+{
+    if (q < 2 || !out) return fail(FHE_ERR_INVALID, "bad arguments");
+    host::const_ratio(q, out);
+    return FHE_OK;
+}
+
+int fhe_min_primitive_root(uint64_t q, uint64_t order, uint64_t *out)
+{
+    if (!out || !host::min_primitive_root(q, order, *out)) return fail(FHE_ERR_INVALID, "no primitive root of that order");
+    return FHE_OK;
+}
+
+int fhe_root_powers(uint64_t q, int log_n, uint64_t *rp, uint64_t *rp_shoup)
+{
+    if (log_n < 1 || log_n > 30 || q < 2) return fail(FHE_ERR_INVALID, "bad arguments");
+    u64 psi;
+    if (!host::min_primitive_root(q, (u64)2 << log_n, psi)) return fail(FHE_ERR_INVALID, "q is not 1 mod 2N (or not prime)");
+    const size_t N = (size_t)1 << log_n;
+    std::vector<u64> t(N);
+    host::root_powers(q, log_n, psi, t.data());
+    for (size_t k = 0; k < N; k++) {
+        if (rp) rp[k] = t[k];
+        if (rp_shoup) rp_shoup[k] = (u64)(((unsigned __int128)t[k] << 64) / q);
+    }
+    return FHE_OK;
+}
+
+// ---------------------------------------------------------------- device tables
+int fhe_ntt_tables_create(fhe_ctx *ctx, int log_n, const uint64_t *q, int count, fhe_ntt_tables **out)
+{
+    if (!ctx || !q || !out || count < 1 || log_n < 1 || log_n > NTT_MAX_LOGN) return fail(FHE_ERR_INVALID, "bad table arguments");
+    const size_t N = (size_t)1 << log_n;
+    std::vector<u64> rows((size_t)count * N), psi(count);
+    for (int l = 0; l < count; l++) {
+        if (!host::min_primitive_root(q[l], (u64)2 * N, psi[l]))
+            return fail(FHE_ERR_INVALID, "modulus " + std::to_string(q[l]) + " has no primitive 2N-th root");
+        host::root_powers(q[l], log_n, psi[l], rows.data() + (size_t)l * N);
+    }
+    return build_tables(ctx, log_n, q, count, rows.data(), true, -1, psi.data(), out);
+}
+
+int fhe_ntt_tables_create_from_roots(fhe_ctx *ctx, int log_n, const uint64_t *q, int count, const uint64_t *root_powers,
+                                     int force_path, fhe_ntt_tables **out)
+{
+    if (!root_powers) return fail(FHE_ERR_INVALID, "null root powers");
+    if (force_path < -1 || force_path > 1) return fail(FHE_ERR_INVALID, "bad force_path");
+    std::vector<u64> psi(count > 0 ? count : 0);
+    if (log_n >= 1 && count >= 1)
+        for (int l = 0; l < count; l++) psi[l] = root_powers[((size_t)l << log_n) + ((size_t)1 << (log_n - 1))];
+    return build_tables(ctx, log_n, q, count, root_powers, true, force_path, psi.data(), out);
+}
+
+int fhe_ntt_tables_destroy(fhe_ntt_tables *t)
+{
+    if (t) {
+        (void)hipSetDevice(t->ctx->device);
+        delete t;
+    }
+    return FHE_OK;
+}
+
+int fhe_ntt_tables_info(const fhe_ntt_tables *t, int *log_n, int *count, int *out_path, uint64_t *out_psi)
+{
+    if (!t) return fail(FHE_ERR_INVALID, "null tables");
+    if (log_n) *log_n = t->log_n;
+    if (count) *count = t->count;
+    for (int l = 0; l < t->count; l++) {
+        if (out_path) out_path[l] = t->path[l];
+        if (out_psi) out_psi[l] = t->psi[l];
+    }
+    return FHE_OK;
+}
+
+// ---------------------------------------------------------------- transforms
+int fhe_ntt_forward_inplace(fhe_ctx *ctx, uint64_t *d, const fhe_ntt_tables *t, size_t limbs, size_t start_idx, void *stream)
+{
+    return ntt_batch(ctx, d, t, 1, limbs, start_idx, stream, false);
+}
+int fhe_ntt_inverse_inplace(fhe_ctx *ctx, uint64_t *d, const fhe_ntt_tables *t, size_t limbs, size_t start_idx, void *stream)
+{
+    return ntt_batch(ctx, d, t, 1, limbs, start_idx, stream, true);
+}
+int fhe_ntt_forward_batch(fhe_ctx *ctx, uint64_t *d, const fhe_ntt_tables *t, size_t n_poly, size_t limbs, size_t start_idx,
+                          void *stream)
+{
+    return ntt_batch(ctx, d, t, n_poly, limbs, start_idx, stream, false);
+}
+int fhe_ntt_inverse_batch(fhe_ctx *ctx, uint64_t *d, const fhe_ntt_tables *t, size_t n_poly, size_t limbs, size_t start_idx,
+                          void *stream)
+{
+    return ntt_batch(ctx, d, t, n_poly, limbs, start_idx, stream, true);
+}
+
+int fhe_bitrev_permute(fhe_ctx *ctx, uint64_t *d_dst, const uint64_t *d_src, int log_n, size_t n_vec, void *stream)
+{
+    if (!ctx || !d_dst || !d_src || d_dst == d_src || log_n < 0 || log_n > 30) return fail(FHE_ERR_INVALID, "bad arguments");
+    HIP_TRY(hipSetDevice(ctx->device));
+    hipError_t e = launch_bitrev_scale(pick(ctx, stream), d_dst, d_src, log_n, (u32)n_vec, ModConst{1, 0, 0}, 1, false);
+    if (e != hipSuccess) return hip_fail(e, "launch_bitrev_scale");
+    return FHE_OK;
+}
+
+int fhe_ntt_cyclic(fhe_ctx *ctx, uint64_t *d_data, uint64_t *d_scratch, int log_n, size_t n_vec, uint64_t mod, uint64_t root,
+                   int convention, int inverse, void *stream)
+{
+    if (!ctx || !d_data || !d_scratch) return fail(FHE_ERR_INVALID, "null argument");
+    if (log_n < 1 || log_n > NTT_MAX_LOGN || mod < 2 || (convention != 0 && convention != 1))
+        return fail(FHE_ERR_INVALID, "bad cyclic NTT arguments");
+    if (!n_vec) return FHE_OK;
+    const u64 n = (u64)1 << log_n;
+    u64 use_root = root % mod, scale = 1;
+    if (inverse) {
+        // motivation/bsgs.py:31-36: inv_root = root^(mod-2), inv_n = n^(mod-2)
+        use_root = host::pow_mod(root, mod - 2, mod);
+        scale = host::pow_mod(n % mod, mod - 2, mod);
+    }
+    fhe_ntt_tables *t = nullptr;
+    {
+        std::lock_guard<std::mutex> lock(ctx->mu);
+        auto key = std::make_tuple(log_n, (u64)mod, use_root, convention);
+        auto it = ctx->cyclic.find(key);
+        if (it == ctx->cyclic.end()) {
+            std::vector<u64> tw(n);
+            host::cyclic_table(mod, log_n, use_root, convention == 1, tw.data());
+            fhe_ntt_tables *nt = nullptr;
+            u64 q = mod;
+            int rc = build_tables(ctx, log_n, &q, 1, tw.data(), false, -1, nullptr, &nt);
+            if (rc) return rc;
+            it = ctx->cyclic.emplace(key, std::unique_ptr<fhe_ntt_tables>(nt)).first;
+        }
+        t = it->second.get();
+    }
+    HIP_TRY(hipSetDevice(ctx->device));
+    hipStream_t st = pick(ctx, stream);
+    PassArgs a{d_data, t->d_lp.as<LimbParams>(), 0u, 1u, (u32)n_vec, 1u};
+    hipError_t e = launch_ntt(st, a, log_n, false, t->path[0]);
+    if (e != hipSuccess) return hip_fail(e, "launch_ntt(cyclic)");
+    e = launch_bitrev_scale(st, d_scratch, d_data, log_n, (u32)n_vec, mod_const(mod), scale, inverse != 0);
+    if (e != hipSuccess) return hip_fail(e, "launch_bitrev_scale");
+    HIP_TRY(hipMemcpyAsync(d_data, d_scratch, n_vec * n * sizeof(u64), hipMemcpyDeviceToDevice, st));
+    return FHE_OK;
+}
+
+// ---------------------------------------------------------------- four-step
+int fhe_fourstep_create(fhe_ctx *ctx, uint64_t n1, uint64_t n2, uint64_t mod, uint64_t g, fhe_fourstep **out)
+{
+    if (!ctx || !out) return fail(FHE_ERR_INVALID, "null argument");
+    const int l1 = ilog2_exact(n1), l2 = ilog2_exact(n2);
+    if (l1 < 1 || l2 < 1 || l1 > NTT_MAX_LOGN || l2 > NTT_MAX_LOGN || l1 + l2 > 26 || mod < 2)
+        return fail(FHE_ERR_INVALID, "n1 and n2 must be powers of two >= 2");
+    const u64 N = n1 * n2;
+    if ((mod - 1) % N) return fail(FHE_ERR_INVALID, "N must divide mod - 1");
+    std::unique_ptr<fhe_fourstep> p(new fhe_fourstep);
+    p->ctx = ctx;
+    p->n1 = n1;
+    p->n2 = n2;
+    p->mod = mod;
+    p->log1 = l1;
+    p->log2 = l2;
+    p->mc = mod_const(mod);
+    // sub-transforms: length n2 with root w^n1 and length n1 with root w^n2 are both
+    // "generator" transforms of g (four_step_ntt_prot.py:76-78): wlen(len) = g^((mod-1)/len)
+    std::vector<u64> tw2(n2), tw1(n1);
+    host::cyclic_table(mod, l2, g, false, tw2.data());
+    host::cyclic_table(mod, l1, g, false, tw1.data());
+    u64 q = mod;
+    int rc = build_tables(ctx, l2, &q, 1, tw2.data(), false, -1, nullptr, &p->t2);
+    if (rc) return rc;
+    rc = build_tables(ctx, l1, &q, 1, tw1.data(), false, -1, nullptr, &p->t1);
+    if (rc) {
+        fhe_ntt_tables_destroy(p->t2);
+        return rc;
+    }
+    // C[t1][k2] = B[t1][k2] * w^(k2*t1)  (four_step_ntt_prot.py:93)
+    const u64 w = host::pow_mod(g, (mod - 1) / N, mod);
+    std::vector<u64> tw(N);
+    for (u64 t1 = 0; t1 < n1; t1++) {
+        const u64 step = host::pow_mod(w, t1, mod);
+        u64 cur = 1 % mod;
+        for (u64 k2 = 0; k2 < n2; k2++) {
+            tw[t1 * n2 + k2] = cur;
+            cur = host::mul_mod(cur, step, mod);
+        }
+    }
+    HIP_TRY(hipSetDevice(ctx->device));
+    HIP_TRY(p->tw.upload(tw));
+    HIP_TRY(p->buf0.alloc(N * sizeof(u64)));
+    HIP_TRY(p->buf1.alloc(N * sizeof(u64)));
+    *out = p.release();
+    return FHE_OK;
+}
+
+int fhe_fourstep_destroy(fhe_fourstep *p)
+{
+    if (p) {
+        (void)hipSetDevice(p->ctx->device);
+        fhe_ntt_tables_destroy(p->t1);
+        fhe_ntt_tables_destroy(p->t2);
+        delete p;
+    }
+    return FHE_OK;
+}
+
+int fhe_fourstep_ntt(fhe_ctx *ctx, uint64_t *d_dst, const uint64_t *d_src, fhe_fourstep *p, void *stream)
+{
+    if (!ctx || !d_dst || !d_src || !p) return fail(FHE_ERR_INVALID, "null argument");
+    HIP_TRY(hipSetDevice(ctx->device));
+    hipStream_t st = pick(ctx, stream);
+    u64 *b0 = p->buf0.as<u64>(), *b1 = p->buf1.as<u64>();
+    const u32 n1 = (u32)p->n1, n2 = (u32)p->n2;
+    hipError_t e;
+    // A[t2][t1] = a[t1 + n1 t2] (:81) -> b0[t1][t2]
+    if ((e = launch_transpose(st, b0, d_src, n2, n1)) != hipSuccess) return hip_fail(e, "transpose");
+    // step 1 (:84-90): n1 transforms of length n2 along t2; output bit-reversed in k2
+    PassArgs a1{b0, p->t2->d_lp.as<LimbParams>(), 0u, 1u, n1, 1u};
+    if ((e = launch_ntt(st, a1, p->log2, false, p->t2->path[0])) != hipSuccess) return hip_fail(e, "four-step column transforms");
+    // step 2 (:93) fused with the reordering: b1[k2][t1] = b0[t1][bitrev(k2)] * w^(k2 t1)
+    if ((e = launch_fourstep_mid(st, b1, b0, n1, n2, p->log2, p->tw.as<u64>(), p->mc, true)) != hipSuccess)
+        return hip_fail(e, "four-step twiddle");
+    // step 3 (:96-102): n2 transforms of length n1 along t1
+    PassArgs a2{b1, p->t1->d_lp.as<LimbParams>(), 0u, 1u, n2, 1u};
+    if ((e = launch_ntt(st, a2, p->log1, false, p->t1->path[0])) != hipSuccess) return hip_fail(e, "four-step row transforms");
+    // step 4 (:105-108): y[k1*n2 + k2] = Y[k1][k2] = b1[k2][bitrev(k1)]
+    if ((e = launch_fourstep_mid(st, d_dst, b1, n2, n1, p->log1, nullptr, p->mc, false)) != hipSuccess)
+        return hip_fail(e, "four-step output reorder");
+    return FHE_OK;
+}
+
+// ---------------------------------------------------------------- pointwise
+int fhe_modmul(fhe_ctx *ctx, uint64_t *c, const uint64_t *a, const uint64_t *b, const fhe_ntt_tables *t, size_t n_poly,
+               size_t limbs, size_t start_idx, void *stream)
+{
+    return pointwise(ctx, c, a, b, t, n_poly, limbs, start_idx, stream, false);
+}
+int fhe_modmul_acc(fhe_ctx *ctx, uint64_t *c, const uint64_t *a, const uint64_t *b, const fhe_ntt_tables *t, size_t n_poly,
+                   size_t limbs, size_t start_idx, void *stream)
+{
+    return pointwise(ctx, c, a, b, t, n_poly, limbs, start_idx, stream, true);
+}
+
+int fhe_polymul(fhe_ctx *ctx, uint64_t *c, uint64_t *a, uint64_t *b, const fhe_ntt_tables *t, size_t n_poly, size_t limbs,
+                size_t start_idx, void *stream)
+{
+    int rc;
+    if ((rc = ntt_batch(ctx, a, t, n_poly, limbs, start_idx, stream, false))) return rc;
+    if (b != a && (rc = ntt_batch(ctx, b, t, n_poly, limbs, start_idx, stream, false))) return rc;
+    if ((rc = pointwise(ctx, c, a, b, t, n_poly, limbs, start_idx, stream, false))) return rc;
+    return ntt_batch(ctx, c, t, n_poly, limbs, start_idx, stream, true);
+}
+
+// ---------------------------------------------------------------- base conversion
+int fhe_baseconv_create(fhe_ctx *ctx, const uint64_t *mod_in, int m, const uint64_t *mod_out, int k, fhe_baseconv **out)
+{
+    if (!ctx || !mod_in || !mod_out || !out || m < 1 || k < 1 || m > 64 || k > 64) return fail(FHE_ERR_INVALID, "bad base conversion arguments");
+    std::unique_ptr<fhe_baseconv> p(new fhe_baseconv);
+    p->m = m;
+    p->k = k;
+    std::vector<u64> mi(mod_in, mod_in + m), mo(mod_out, mod_out + k), ri(2 * m), ro(2 * k), ipp((size_t)m * m, 0), pq((size_t)m * k),
+        fc((size_t)m * k), fs((size_t)m * k);
+    u64 maxq = 0;
+    for (int j = 0; j < m; j++) {
+        if (mi[j] < 2 || mi[j] >= ((u64)1 << 62)) return fail(FHE_ERR_UNSUPPORTED, "input modulus out of range");
+        u64 cr[3];
+        host::const_ratio(mi[j], cr);
+        ri[2 * j] = cr[0];
+        ri[2 * j + 1] = cr[1];
+    }
+    for (int o = 0; o < k; o++) {
+        if (mo[o] < 2 || mo[o] >= ((u64)1 << 62)) return fail(FHE_ERR_UNSUPPORTED, "output modulus out of range");
+        u64 cr[3];
+        host::const_ratio(mo[o], cr);
+        ro[2 * o] = cr[0];
+        ro[2 * o + 1] = cr[1];
+        maxq = mo[o] > maxq ? mo[o] : maxq;
+    }
+    for (int l = 0; l < m; l++)
+        for (int j = l + 1; j < m; j++) {
+            const u64 inv = host::inv_mod(mi[l] % mi[j], mi[j]);
+            if (!inv && mi[j] != 1) return fail(FHE_ERR_INVALID, "input moduli must be pairwise coprime");
+            ipp[(size_t)l * m + j] = inv;
+        }
+    for (int l = 0; l < m; l++)
+        for (int o = 0; o < k; o++) pq[(size_t)l * k + o] = mi[l] % mo[o];
+    // rfhe_framewk/src/baseConv.py:17-18: hat_p[j] = P // p_j, inv_hat_p[j] = hat_p[j]^-1 mod p_j
+    for (int j = 0; j < m; j++) {
+        u64 hat_pj = 1 % mi[j];
+        for (int l = 0; l < m; l++)
+            if (l != j) hat_pj = host::mul_mod(hat_pj, mi[l] % mi[j], mi[j]);
+        const u64 inv = host::inv_mod(hat_pj, mi[j]);
+        for (int o = 0; o < k; o++) {
+            u64 hat_q = 1 % mo[o];
+            for (int l = 0; l < m; l++)
+                if (l != j) hat_q = host::mul_mod(hat_q, mi[l] % mo[o], mo[o]);
+            const u64 coef = host::mul_mod(hat_q, inv % mo[o], mo[o]);
+            fc[(size_t)j * k + o] = coef;
+            fs[(size_t)j * k + o] = (u64)(((unsigned __int128)coef << 64) / mo[o]);
+        }
+    }
+    p->fast_ok = (unsigned __int128)maxq * (u64)m < ((unsigned __int128)1 << 64);
+    HIP_TRY(hipSetDevice(ctx->device));
+    HIP_TRY(p->mod_in.upload(mi));
+    HIP_TRY(p->mod_out.upload(mo));
+    HIP_TRY(p->ratio_in.upload(ri));
+    HIP_TRY(p->ratio_out.upload(ro));
+    HIP_TRY(p->inv_pl_pj.upload(ipp));
+    HIP_TRY(p->pl_qo.upload(pq));
+    HIP_TRY(p->fast_coef.upload(fc));
+    HIP_TRY(p->fast_shoup.upload(fs));
+    p->dev = BaseConvPlanDev{m, k, p->mod_in.as<u64>(), p->mod_out.as<u64>(), p->ratio_in.as<u64>(), p->ratio_out.as<u64>(),
+                             p->inv_pl_pj.as<u64>(), p->pl_qo.as<u64>(), p->fast_coef.as<u64>(), p->fast_shoup.as<u64>()};
+    *out = p.release();
+    return FHE_OK;
+}
+
+int fhe_baseconv_destroy(fhe_baseconv *p)
+{
+    delete p;
+    return FHE_OK;
+}
+
+int fhe_baseconv_exact(fhe_ctx *ctx, uint64_t *d_out, const uint64_t *d_in, const fhe_baseconv *p, size_t N, void *stream)
+{
+    if (!ctx || !d_out || !d_in || !p) return fail(FHE_ERR_INVALID, "null argument");
+    HIP_TRY(hipSetDevice(ctx->device));
+    hipError_t e = launch_baseconv_exact(pick(ctx, stream), d_out, d_in, p->dev, N);
+    if (e != hipSuccess) return hip_fail(e, "launch_baseconv_exact");
+    return FHE_OK;
+}
+
+int fhe_baseconv_fast(fhe_ctx *ctx, uint64_t *d_out, const uint64_t *d_in, const fhe_baseconv *p, size_t N, void *stream)
+{
+    if (!ctx || !d_out || !d_in || !p) return fail(FHE_ERR_INVALID, "null argument");
+    if (!p->fast_ok) return fail(FHE_ERR_UNSUPPORTED, "unreduced sum would exceed 64 bits (m * max q >= 2^64)");
+    HIP_TRY(hipSetDevice(ctx->device));
+    hipError_t e = launch_bconv_fast(pick(ctx, stream), d_out, d_in, p->dev, N);
+    if (e != hipSuccess) return hip_fail(e, "launch_bconv_fast");
+    return FHE_OK;
+}
+
+int fhe_crt_garner(fhe_ctx *ctx, uint64_t *d_x_lo, uint64_t *d_x_hi, const uint64_t *d_residues, const uint64_t *moduli, int m,
+                   size_t N, void *stream)
+{
+    if (!ctx || !d_x_lo || !d_x_hi || !d_residues || !moduli) return fail(FHE_ERR_INVALID, "null argument");
+    if (m < 1 || m > 16) return fail(FHE_ERR_UNSUPPORTED, "crt_garner supports 1..16 limbs");
+    GarnerTables *g = nullptr;
+    {
+        std::lock_guard<std::mutex> lock(ctx->mu);
+        std::vector<u64> key(moduli, moduli + m);
+        auto it = ctx->garner.find(key);
+        if (it == ctx->garner.end()) {
+            // rfhe_framewk/src/baseConv.cu:157-169
+            std::vector<u64> ratio(2 * m), plo(m), phi(m), inv(m, 0);
+            unsigned __int128 pref = 1;
+            for (int j = 0; j < m; j++) {
+                if (moduli[j] < 2 || moduli[j] >= ((u64)1 << 62)) return fail(FHE_ERR_UNSUPPORTED, "modulus out of range");
+                u64 cr[3];
+                host::const_ratio(moduli[j], cr);
+                ratio[2 * j] = cr[0];
+                ratio[2 * j + 1] = cr[1];
+                plo[j] = (u64)pref;
+                phi[j] = (u64)(pref >> 64);
+                if (j >= 1) {
+                    inv[j] = host::inv_mod((u64)(pref % moduli[j]), moduli[j]);
+                    if (!inv[j]) return fail(FHE_ERR_INVALID, "prefix product not invertible modulo p_j");
+                }
+                pref *= moduli[j];
+            }
+            std::unique_ptr<GarnerTables> nt(new GarnerTables);
+            HIP_TRY(hipSetDevice(ctx->device));
+            HIP_TRY(nt->mod.upload(key));
+            HIP_TRY(nt->ratio.upload(ratio));
+            HIP_TRY(nt->pref_lo.upload(plo));
+            HIP_TRY(nt->pref_hi.upload(phi));
+            HIP_TRY(nt->inv_pref.upload(inv));
+            it = ctx->garner.emplace(key, std::move(nt)).first;
+        }
+        g = it->second.get();
+    }
+    HIP_TRY(hipSetDevice(ctx->device));
+    hipError_t e = launch_crt_garner(pick(ctx, stream), d_x_lo, d_x_hi, d_residues, g->mod.as<u64>(), g->ratio.as<u64>(),
+                                     g->pref_lo.as<u64>(), g->pref_hi.as<u64>(), g->inv_pref.as<u64>(), m, N);
+    if (e != hipSuccess) return hip_fail(e, "launch_crt_garner");
+    return FHE_OK;
+}
+
+int fhe_bsgs_hadamard(fhe_ctx *ctx, uint64_t *d_y, const uint64_t *d_M_blocks, const uint64_t *d_v, int k, int block_size,
+                      uint64_t mod, void *stream)
+{
+    if (!ctx || !d_y || !d_M_blocks || !d_v || k < 1 || block_size < 1) return fail(FHE_ERR_INVALID, "bad arguments");
+    HIP_TRY(hipSetDevice(ctx->device));
+    ModConst mc = mod >= 2 ? mod_const(mod) : ModConst{1, 0, 0};
+    hipError_t e = launch_bsgs_hadamard(pick(ctx, stream), d_y, d_M_blocks, d_v, k, block_size, mod >= 2 ? &mc : nullptr);
+    if (e != hipSuccess) return hip_fail(e, "launch_bsgs_hadamard");
+    return FHE_OK;
+}
+
+int fhe_flip_bit(fhe_ctx *ctx, uint64_t *d_data, uint64_t idx, int bit, void *stream)
+{
+    if (!ctx || !d_data || bit < 0 || bit > 63) return fail(FHE_ERR_INVALID, "bad arguments");
+    HIP_TRY(hipSetDevice(ctx->device));
+    hipError_t e = launch_flip_bit(pick(ctx, stream), d_data, idx, bit);
+    if (e != hipSuccess) return hip_fail(e, "launch_flip_bit");
+    return FHE_OK;
+}
+
+} // extern "C"

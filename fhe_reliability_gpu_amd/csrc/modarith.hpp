@@ -1,0 +1,200 @@
+// modarith.hpp -- modular arithmetic policies shared by every kernel.
+//
+// Two arithmetic paths, chosen per RNS limb when the tables are built:
+//
+//  * ArithF64  (q < 2^50, the size the reference uses: reliability_test/ntt_test.cu:44
+//    creates 50-bit primes).  Residues live in FP64 registers as exact integers in
+//    a signed lazy range; a modular multiply is 6 FP64 ops (2 mul, 1 rndne, 2 fma,
+//    1 add) on the half-rate FP64 pipe of CDNA4 instead of ~10 quarter-rate 32-bit
+//    integer multiplies.  Every intermediate is an exactly representable integer
+//    (|x| < 2^53), so the result is bit-exact, not approximate.
+//  * ArithU64  (q < 2^61): Harvey lazy butterflies with Shoup twiddle quotients,
+//    values in [0,4q).
+//
+// The file compiles under hipcc (device) and under g++ (tests/emu: the same
+// template code run thread-by-thread on the CPU to check indexing and bounds).
+// Contraction must be off (-ffp-contract=off): the algorithm needs the individually
+// rounded product h = a*w next to fma(a,w,-h).
+#pragma once
+#include <cstddef>
+#include <cstdint>
+
+#if defined(__HIPCC__)
+#include <hip/hip_runtime.h>
+#define FHE_HD __host__ __device__ __forceinline__
+#define FHE_D __device__ __forceinline__
+#else
+#define FHE_HD inline
+#define FHE_D inline
+#endif
+
+namespace fhe {
+
+typedef uint64_t u64;
+typedef uint32_t u32;
+
+// One twiddle = 16 bytes so a single dwordx4 load fetches the factor and its
+// precomputed quotient.  ArithU64: {w, floor(w*2^64/q)}; ArithF64: {bits(w), bits(w/q)}.
+struct alignas(16) Tw {
+    u64 a, b;
+};
+
+// Per-limb constants, resident in device memory next to the tables.
+struct alignas(16) LimbParams {
+    u64 q;           // modulus
+    u64 two_q;       // 2q (ArithU64)
+    double n;        // (double)q    (ArithF64)
+    double ninv;     // 1.0 / n, correctly rounded
+    Tw inv_n;        // N^-1 mod q encoded as a twiddle of this limb's path
+    const Tw *fwd;   // forward table, N entries, entry k = psi^bitrev(k)  (entry 0 unused)
+    const Tw *inv;   // inverse table, entry k = fwd[k]^-1
+    u64 barrett_lo;  // floor(2^128/q) low / high words (Modulus::const_ratio, ntt_test.cu:49-53)
+    u64 barrett_hi;
+    int path;        // 0 = ArithF64, 1 = ArithU64
+    int pad_;
+    u64 pad2_;
+};
+
+enum { PATH_F64 = 0, PATH_U64 = 1 };
+
+FHE_HD u64 mulhi64(u64 a, u64 b)
+{
+#if defined(__HIP_DEVICE_COMPILE__)
+    return __umul64hi(a, b);
+#else
+    return (u64)(((unsigned __int128)a * b) >> 64);
+#endif
+}
+
+FHE_HD double u64_bits_to_double(u64 b) { return __builtin_bit_cast(double, b); }
+FHE_HD u64 double_to_u64_bits(double d) { return __builtin_bit_cast(u64, d); }
+
+// Full reduction of an arbitrary 64-bit word (only reached for out-of-range inputs,
+// e.g. the bit-flipped symbols of reliability_test/ntt_test.cu:104-135).
+FHE_HD u64 reduce_any_u64(u64 x, u64 q) { return x % q; }
+
+// ---------------------------------------------------------------------------
+// ArithF64
+// ---------------------------------------------------------------------------
+struct ArithF64 {
+    typedef double elem;
+    static constexpr int PATH = PATH_F64;
+    // Growth bound bookkeeping (units of q), see DESIGN.md "lazy FP64 ranges":
+    // forward butterfly  B' = B + 0.5 + B*q*2^-52 <= 1.25 B + 0.5  -> from canonical input 5
+    // stages, after a reduce() 6 stages stay below 8q < 2^53.
+    // inverse butterfly  B' = 2B                                    -> 2 resp. 3 stages.
+    static constexpr int FWD_FIRST = 5, FWD_NEXT = 6, INV_FIRST = 2, INV_NEXT = 3;
+
+    struct Ctx {
+        double n, ninv;
+        u64 q;
+    };
+    static FHE_HD Ctx make_ctx(const LimbParams &p) { return Ctx{p.n, p.ninv, p.q}; }
+
+    static FHE_HD bool in_range(u64 raw, const Ctx &c) { return raw < c.q; }
+    // raw < q < 2^50: OR the exponent of 2^52 into the high word, subtract 2^52.
+    static FHE_HD elem from_canonical(u64 raw) { return u64_bits_to_double(raw | 0x4330000000000000ull) - 4503599627370496.0; }
+    // x integer in [0, 2^52)
+    static FHE_HD u64 to_u64(elem x) { return double_to_u64_bits(x + 4503599627370496.0) & 0x000FFFFFFFFFFFFFull; }
+    static FHE_HD elem load_lazy(u64 raw) { return u64_bits_to_double(raw); }   // between passes: raw double bits
+    static FHE_HD u64 store_lazy(elem x) { return double_to_u64_bits(x); }
+
+    // x -> x - q*rint(x/q): |result| <= q/2 (+1 ulp of the quotient, harmless)
+    static FHE_HD void reduce(elem &x, const Ctx &c)
+    {
+        double k = __builtin_rint(x * c.ninv);
+        x = __builtin_fma(-k, c.n, x);
+    }
+    static FHE_HD u64 canonical(elem x, const Ctx &c)
+    {
+        reduce(x, c);
+        if (x < 0.0) x += c.n;
+        return to_u64(x);
+    }
+    // a*w mod q in (-q(0.5+|a|2^-52), +...): exact integer arithmetic in FP64
+    static FHE_HD elem mulmod(elem a, const Tw &t, const Ctx &c)
+    {
+        double w = u64_bits_to_double(t.a), wp = u64_bits_to_double(t.b);
+        double h = a * w;
+        double k = __builtin_rint(a * wp);
+        double l = __builtin_fma(a, w, -h);
+        double r = __builtin_fma(-k, c.n, h);
+        return r + l;
+    }
+    // Cooley-Tukey: (X, Y) -> (X + wY, X - wY)
+    static FHE_HD void bfly_fwd(elem &X, elem &Y, const Tw &t, const Ctx &c)
+    {
+        double v = mulmod(Y, t, c);
+        double x = X;
+        X = x + v;
+        Y = x - v;
+    }
+    // Gentleman-Sande: (X, Y) -> (X + Y, (X - Y) w)
+    static FHE_HD void bfly_inv(elem &X, elem &Y, const Tw &t, const Ctx &c)
+    {
+        double s = X + Y, d = X - Y;
+        X = s;
+        Y = mulmod(d, t, c);
+    }
+    static FHE_HD elem add(elem a, elem b) { return a + b; }
+    // host: encode a residue w (< q) as a twiddle
+    static inline Tw encode(u64 w, u64 q)
+    {
+        double dw = (double)w, dq = (double)q;
+        return Tw{double_to_u64_bits(dw), double_to_u64_bits(dw / dq)};
+    }
+};
+
+// ---------------------------------------------------------------------------
+// ArithU64
+// ---------------------------------------------------------------------------
+struct ArithU64 {
+    typedef u64 elem;
+    static constexpr int PATH = PATH_U64;
+    static constexpr int FWD_FIRST = 1 << 20, FWD_NEXT = 1 << 20, INV_FIRST = 1 << 20, INV_NEXT = 1 << 20;
+
+    struct Ctx {
+        u64 q, two_q;
+    };
+    static FHE_HD Ctx make_ctx(const LimbParams &p) { return Ctx{p.q, p.two_q}; }
+
+    static FHE_HD bool in_range(u64 raw, const Ctx &c) { return raw < c.q; }
+    static FHE_HD elem from_canonical(u64 raw) { return raw; }
+    static FHE_HD elem load_lazy(u64 raw) { return raw; }   // [0,4q) forward, [0,2q) inverse
+    static FHE_HD u64 store_lazy(elem x) { return x; }
+    static FHE_HD void reduce(elem &, const Ctx &) {}
+    static FHE_HD u64 canonical(elem x, const Ctx &c)
+    {
+        x = x >= c.two_q ? x - c.two_q : x;
+        return x >= c.q ? x - c.q : x;
+    }
+    // Shoup lazy product: result in [0, 2q) for ANY 64-bit a
+    static FHE_HD elem mulmod(elem a, const Tw &t, const Ctx &c)
+    {
+        u64 qh = mulhi64(a, t.b);
+        return a * t.a - qh * c.q;
+    }
+    // Harvey CT: inputs/outputs in [0, 4q)
+    static FHE_HD void bfly_fwd(elem &X, elem &Y, const Tw &t, const Ctx &c)
+    {
+        u64 x = X >= c.two_q ? X - c.two_q : X;
+        u64 v = mulmod(Y, t, c);
+        X = x + v;
+        Y = x - v + c.two_q;
+    }
+    // Harvey GS: inputs/outputs in [0, 2q)
+    static FHE_HD void bfly_inv(elem &X, elem &Y, const Tw &t, const Ctx &c)
+    {
+        u64 s = X + Y;
+        u64 d = X - Y + c.two_q;
+        X = s >= c.two_q ? s - c.two_q : s;
+        Y = mulmod(d, t, c);
+    }
+    static inline Tw encode(u64 w, u64 q) { return Tw{w, (u64)(((unsigned __int128)w << 64) / q)}; }
+};
+
+// The inverse transform of ArithU64 keeps values in [0,2q): entering it needs one
+// conditional subtraction from the canonical/[0,4q) range -- inputs are canonical
+// (< q) or reduced through reduce_any_u64, so nothing to do.
+
+} // namespace fhe

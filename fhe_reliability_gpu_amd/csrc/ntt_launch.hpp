@@ -1,0 +1,56 @@
+// ntt_launch.hpp -- host-visible launch entry points of the kernel translation units.
+#pragma once
+#include <hip/hip_runtime.h>
+
+#include "ntt_plan.hpp"
+
+namespace fhe {
+
+// Batched in-place transform of a.units limbs of 2^logn points, all on `path`.
+hipError_t launch_ntt(hipStream_t st, const PassArgs &a, int logn, bool inverse, int path);
+
+// ---- aux_kernels.hip --------------------------------------------------------
+struct PointwiseArgs {
+    u64 *c;
+    const u64 *a;
+    const u64 *b;
+    const LimbParams *lp;
+    u32 limb0, limbs, units, poly_stride;
+    int logn;
+};
+// c = a*b mod q (accumulate = false) or c = (c + a*b) mod q (accumulate = true), per limb
+hipError_t launch_modmul(hipStream_t st, const PointwiseArgs &p, bool accumulate);
+// data[idx] ^= 1 << bit  (reliability_test/dotprod_test.cu:31-33)
+hipError_t launch_flip_bit(hipStream_t st, u64 *data, u64 idx, int bit);
+// modulus + floor(2^128/q) for the Barrett helpers, passed by value
+struct ModConst {
+    u64 q, r0, r1;
+};
+// per unit of 2^logn words: dst[i] = src[bitrev(i)] (* scale mod q when do_scale).  dst != src.
+hipError_t launch_bitrev_scale(hipStream_t st, u64 *dst, const u64 *src, int logn, u32 units, const ModConst &mc, u64 scale,
+                               bool do_scale);
+// out[c][r] = in[r][bitrev(c)] (* tw[r*cols + c])   (four-step twiddle + transpose)
+hipError_t launch_fourstep_mid(hipStream_t st, u64 *out, const u64 *in, u32 rows, u32 cols, int log_cols,
+                               const u64 *tw, const ModConst &mc, bool with_twiddle);
+hipError_t launch_transpose(hipStream_t st, u64 *out, const u64 *in, u32 rows, u32 cols);
+
+// ---- baseconv_kernels.hip ------------------------------------------------------
+struct BaseConvPlanDev {
+    int m, k;
+    const u64 *mod_in;        // m
+    const u64 *mod_out;       // k
+    const u64 *ratio_in;      // m x 2   floor(2^128/p_j)
+    const u64 *ratio_out;     // k x 2
+    const u64 *inv_pl_mod_pj; // m x m   (p_l)^-1 mod p_j  (l < j)
+    const u64 *pl_mod_qo;     // m x k   p_l mod q_o
+    const u64 *fast_coef;     // m x k   (Phat_j * inv_j) mod q_o   (rfhe_framewk/src/baseConv.py:17-29)
+    const u64 *fast_coef_shoup;
+};
+hipError_t launch_baseconv_exact(hipStream_t st, u64 *out, const u64 *in, const BaseConvPlanDev &pl, u64 N);
+hipError_t launch_bconv_fast(hipStream_t st, u64 *out, const u64 *in, const BaseConvPlanDev &pl, u64 N);
+hipError_t launch_crt_garner(hipStream_t st, u64 *x_lo, u64 *x_hi, const u64 *residues, const u64 *moduli,
+                             const u64 *ratios, const u64 *pref_lo, const u64 *pref_hi, const u64 *inv_pref, int m, u64 N);
+hipError_t launch_bsgs_hadamard(hipStream_t st, u64 *y, const u64 *M_blocks, const u64 *v, int k, int bs,
+                                const ModConst *mc /* nullptr: int64 wrap-around like the reference */);
+
+} // namespace fhe

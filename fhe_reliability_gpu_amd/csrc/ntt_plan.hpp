@@ -1,0 +1,102 @@
+// ntt_plan.hpp -- compile-time decomposition of a 2^LOGN transform into passes and
+// register steps, plus the block-level glue shared by the HIP kernels
+// (ntt_kernels.hip) and the CPU emulation used by the tests (tests/emu).
+#pragma once
+#include "ntt_core.hpp"
+
+namespace fhe {
+
+constexpr int NTT_THREADS = 256;
+constexpr int NTT_MAX_LOGN = 20;
+
+// Stage split per size.  Row pass = stages inside contiguous rows of 2^PR points
+// (always present); column pass = the PC leading stages (absent for LOGN <= 12:
+// the whole limb fits one workgroup's LDS and is read and written exactly once).
+template <int LOGN> struct Plan;
+#define FHE_PLAN(LOGN_, C0, C1, C2, R0, R1, R2)                      \
+    template <> struct Plan<LOGN_> {                                 \
+        typedef Steps<C0, C1, C2> Col;                               \
+        typedef Steps<R0, R1, R2> Row;                               \
+        static_assert(Col::P + Row::P == LOGN_, "bad plan");         \
+    };
+FHE_PLAN(1, 0, 0, 0, 1, 0, 0)
+FHE_PLAN(2, 0, 0, 0, 2, 0, 0)
+FHE_PLAN(3, 0, 0, 0, 3, 0, 0)
+FHE_PLAN(4, 0, 0, 0, 4, 0, 0)
+FHE_PLAN(5, 0, 0, 0, 3, 2, 0)
+FHE_PLAN(6, 0, 0, 0, 3, 3, 0)
+FHE_PLAN(7, 0, 0, 0, 4, 3, 0)
+FHE_PLAN(8, 0, 0, 0, 4, 4, 0)
+FHE_PLAN(9, 0, 0, 0, 3, 3, 3)
+FHE_PLAN(10, 0, 0, 0, 4, 3, 3)
+FHE_PLAN(11, 0, 0, 0, 4, 4, 3)
+FHE_PLAN(12, 0, 0, 0, 4, 4, 4)
+FHE_PLAN(13, 3, 2, 0, 4, 4, 0)
+FHE_PLAN(14, 3, 3, 0, 4, 4, 0)
+FHE_PLAN(15, 4, 3, 0, 4, 4, 0)
+FHE_PLAN(16, 4, 4, 0, 4, 4, 0)
+FHE_PLAN(17, 3, 3, 3, 4, 4, 0)
+FHE_PLAN(18, 3, 3, 3, 3, 3, 3)
+FHE_PLAN(19, 4, 3, 3, 3, 3, 3)
+FHE_PLAN(20, 4, 3, 3, 4, 3, 3)
+#undef FHE_PLAN
+
+FHE_HD constexpr int cmin(int a, int b) { return a < b ? a : b; }
+
+template <int LOGN> struct PlanGeom {
+    typedef Plan<LOGN> PL;
+    static constexpr int PC = PL::Col::P, PR = PL::Row::P;
+    static constexpr bool TWO_PASS = PC > 0;
+    // 64 KiB of LDS per workgroup at most
+    static constexpr int TC = TWO_PASS ? cmin(64, 8192 >> PC) : 1;
+    static constexpr int TR = !TWO_PASS ? 1 : PR <= 8 ? 16 : PR == 9 ? 8 : 4;
+};
+
+// What a pass needs to know about the launch.
+struct PassArgs {
+    u64 *data;              // [n_poly][limbs][N]
+    const LimbParams *lp;   // table of all limbs of the table set
+    u32 limb0;              // first modulus index (start_modulus_idx of the Phantom call)
+    u32 limbs;              // limbs of each polynomial handled by this launch (same arithmetic path)
+    u32 units;              // n_poly * limbs
+    u32 poly_stride;        // distance between polynomials in units of one limb (>= limbs)
+};
+
+template <class A, int LOGN, bool INVERSE>
+struct Passes {
+    typedef PlanGeom<LOGN> G;
+    typedef typename G::PL PL;
+    static constexpr u32 RED_FIRST = INVERSE ? reduce_mask(0, G::PR, A::INV_FIRST, A::INV_NEXT)
+                                             : reduce_mask(0, G::TWO_PASS ? G::PC : G::PR, A::FWD_FIRST, A::FWD_NEXT);
+    static constexpr u32 RED_SECOND = INVERSE ? reduce_mask(G::PR, G::PC, A::INV_FIRST, A::INV_NEXT)
+                                              : reduce_mask(G::PC, G::PR, A::FWD_FIRST, A::FWD_NEXT);
+    // single pass
+    typedef RowPass<A, typename PL::Row, LOGN, 1, NTT_THREADS, INVERSE, IO_CANONICAL, IO_CANONICAL, RED_FIRST> Single;
+    // forward: column pass then row pass; inverse: row pass then column pass
+    typedef ColPass<A, typename PL::Col, LOGN, 0, G::TC, NTT_THREADS, INVERSE, INVERSE ? IO_LAZY : IO_CANONICAL,
+                    INVERSE ? IO_CANONICAL : IO_LAZY, INVERSE ? RED_SECOND : RED_FIRST> Col;
+    typedef RowPass<A, typename PL::Row, LOGN, G::TR, NTT_THREADS, INVERSE, INVERSE ? IO_CANONICAL : IO_LAZY,
+                    INVERSE ? IO_LAZY : IO_CANONICAL, INVERSE ? RED_FIRST : RED_SECOND> Row;
+};
+
+// Block -> work mapping.  One block = one tile of one unit (unit = one limb of one
+// polynomial); the tiles of a unit are adjacent block indices.
+template <class CP, int LOGN>
+FHE_D u64 *col_tile(u32 block, const PassArgs &a, u32 &limb)
+{
+    const u32 unit = block / CP::TILES, tile = block % CP::TILES;
+    const u32 poly = unit / a.limbs, l = unit % a.limbs;
+    limb = a.limb0 + l;
+    return a.data + (((size_t)poly * a.poly_stride + l) << LOGN) + (size_t)tile * CP::TCOLS;
+}
+template <class RP, int LOGN>
+FHE_D u64 *row_tile(u32 block, const PassArgs &a, u32 &limb, u32 &row0)
+{
+    const u32 unit = block / RP::TILES, tile = block % RP::TILES;
+    const u32 poly = unit / a.limbs, l = unit % a.limbs;
+    limb = a.limb0 + l;
+    row0 = tile * RP::TROWS;
+    return a.data + (((size_t)poly * a.poly_stride + l) << LOGN) + (size_t)row0 * RP::NPTS;
+}
+
+} // namespace fhe

@@ -1,0 +1,370 @@
+"""Python host over the C ABI (``_lib``): device buffers, table sets and the
+reference's Python-level operator names, so that code written against
+``motivation/{ntt,baseConv,bsgs}.py``, ``rfhe_framewk/src/{ntt,negaclic_ntt,baseConv}.py``
+and ``reliability_test/four_step_ntt_prot.py`` can switch to the GPU engine by
+changing an import.  Every function here ends in HIP kernel launches; nothing is
+computed on the CPU apart from packing/unpacking lists.
+"""
+from __future__ import annotations
+
+import ctypes as C
+from typing import List, Optional, Sequence
+
+import numpy as np
+
+from . import _lib
+from ._lib import check, lib, p64, u64, vp
+
+_U64 = np.uint64
+
+
+def _arr(x) -> np.ndarray:
+    return np.ascontiguousarray(np.asarray(x, dtype=_U64))
+
+
+def _ptr(a: np.ndarray):
+    return a.ctypes.data_as(p64)
+
+
+class Engine:
+    """One HIP device + stream (``phantom::util::cuda_stream_wrapper``, ntt_test.cu:40-41)."""
+
+    def __init__(self, device: int = 0):
+        h = vp()
+        check(lib.fhe_ctx_create(device, C.byref(h)))
+        self._h = h
+        self.device = device
+        s = vp()
+        check(lib.fhe_ctx_stream(h, C.byref(s)))
+        self.stream = s
+
+    def close(self):
+        if getattr(self, "_h", None):
+            lib.fhe_ctx_destroy(self._h)
+            self._h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    # -- memory ------------------------------------------------------------
+    def alloc(self, n_words: int) -> "DeviceArray":
+        return DeviceArray(self, n_words)
+
+    def upload(self, host) -> "DeviceArray":
+        a = _arr(host)
+        d = DeviceArray(self, a.size)
+        d.shape = a.shape
+        check(lib.fhe_h2d(self._h, d.ptr, a.ctypes.data, a.nbytes, None))
+        self.sync()  # the NumPy temporary must outlive the async copy
+        return d
+
+    def sync(self, stream=None):
+        check(lib.fhe_sync(self._h, stream))
+
+    # -- tables ------------------------------------------------------------
+    def tables(self, log_n: int, moduli: Sequence[int]) -> "NttTables":
+        return NttTables(self, log_n, moduli)
+
+    def tables_from_roots(self, log_n: int, moduli: Sequence[int], root_powers, force_path: int = -1) -> "NttTables":
+        return NttTables(self, log_n, moduli, root_powers=root_powers, force_path=force_path)
+
+
+class DeviceArray:
+    """uint64 words in HBM, owned through fhe_alloc/fhe_free (make_cuda_auto_ptr, ntt_test.cu:88)."""
+
+    def __init__(self, eng: Engine, n_words: int):
+        self.eng = eng
+        self.size = int(n_words)
+        self.shape = (self.size,)
+        p = vp()
+        check(lib.fhe_alloc(eng._h, self.size * 8, C.byref(p)))
+        self.ptr = p
+
+    def download(self) -> np.ndarray:
+        out = np.empty(self.size, dtype=_U64)
+        check(lib.fhe_d2h(self.eng._h, out.ctypes.data, self.ptr, out.nbytes, None))
+        self.eng.sync()
+        return out.reshape(self.shape)
+
+    def copy_from(self, other: "DeviceArray"):
+        check(lib.fhe_d2d(self.eng._h, self.ptr, other.ptr, min(self.size, other.size) * 8, None))
+
+    def free(self):
+        if self.ptr:
+            lib.fhe_free(self.eng._h, self.ptr)
+            self.ptr = None
+
+    def __del__(self):
+        try:
+            if self.eng._h:
+                self.free()
+        except Exception:
+            pass
+
+
+def create_moduli(N: int, bits: Sequence[int]) -> List[int]:
+    """``CoeffModulus::Create(N, {bits...})`` (reliability_test/ntt_test.cu:44)."""
+    b = (C.c_int * len(bits))(*bits)
+    out = (u64 * len(bits))()
+    check(lib.fhe_moduli_create(N, b, len(bits), out))
+    return [int(x) for x in out]
+
+
+def min_primitive_root(q: int, order: int) -> int:
+    r = u64()
+    check(lib.fhe_min_primitive_root(q, order, C.byref(r)))
+    return int(r.value)
+
+
+def root_powers(q: int, log_n: int, shoup: bool = False):
+    """``NTT::get_from_root_powers[_shoup]`` (ntt_test.cu:60-64)."""
+    rp = np.zeros(1 << log_n, dtype=_U64)
+    sh = np.zeros(1 << log_n, dtype=_U64)
+    check(lib.fhe_root_powers(q, log_n, _ptr(rp), _ptr(sh)))
+    return (rp, sh) if shoup else rp
+
+
+class NttTables:
+    """``DModulus[]`` + ``DNTTTable`` of a limb set (ntt_test.cu:47-69)."""
+
+    def __init__(self, eng: Engine, log_n: int, moduli: Sequence[int], root_powers=None, force_path: int = -1):
+        self.eng = eng
+        self.log_n = log_n
+        self.N = 1 << log_n
+        self.moduli = [int(q) for q in moduli]
+        q = _arr(self.moduli)
+        h = vp()
+        if root_powers is None:
+            check(lib.fhe_ntt_tables_create(eng._h, log_n, _ptr(q), q.size, C.byref(h)))
+        else:
+            rp = _arr(root_powers).reshape(q.size, self.N)
+            check(lib.fhe_ntt_tables_create_from_roots(eng._h, log_n, _ptr(q), q.size, _ptr(rp), force_path, C.byref(h)))
+        self._h = h
+        paths = (C.c_int * q.size)()
+        psi = (u64 * q.size)()
+        check(lib.fhe_ntt_tables_info(h, None, None, paths, psi))
+        self.paths = list(paths)
+        self.psi = [int(x) for x in psi]
+
+    def __len__(self):
+        return len(self.moduli)
+
+    # nwt_2d_radix8_forward_inplace (ntt_test.cu:95): d is [n_poly][limbs][N]
+    def forward(self, d: DeviceArray, limbs: Optional[int] = None, start: int = 0, n_poly: int = 1, stream=None):
+        limbs = len(self) - start if limbs is None else limbs
+        check(lib.fhe_ntt_forward_batch(self.eng._h, d.ptr, self._h, n_poly, limbs, start, stream))
+
+    def inverse(self, d: DeviceArray, limbs: Optional[int] = None, start: int = 0, n_poly: int = 1, stream=None):
+        limbs = len(self) - start if limbs is None else limbs
+        check(lib.fhe_ntt_inverse_batch(self.eng._h, d.ptr, self._h, n_poly, limbs, start, stream))
+
+    def modmul(self, c: DeviceArray, a: DeviceArray, b: DeviceArray, limbs=None, start=0, n_poly=1, acc=False, stream=None):
+        limbs = len(self) - start if limbs is None else limbs
+        f = lib.fhe_modmul_acc if acc else lib.fhe_modmul
+        check(f(self.eng._h, c.ptr, a.ptr, b.ptr, self._h, n_poly, limbs, start, stream))
+
+    def polymul(self, c: DeviceArray, a: DeviceArray, b: DeviceArray, limbs=None, start=0, n_poly=1, stream=None):
+        limbs = len(self) - start if limbs is None else limbs
+        check(lib.fhe_polymul(self.eng._h, c.ptr, a.ptr, b.ptr, self._h, n_poly, limbs, start, stream))
+
+    def close(self):
+        if getattr(self, "_h", None) and self.eng._h:
+            lib.fhe_ntt_tables_destroy(self._h)
+        self._h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+
+# ---------------------------------------------------------------------------
+# Reference-named operators (lists in, lists out)
+# ---------------------------------------------------------------------------
+_default_engine: Optional[Engine] = None
+
+
+def default_engine() -> Engine:
+    global _default_engine
+    if _default_engine is None:
+        _default_engine = Engine(0)
+    return _default_engine
+
+
+def _log2(n: int) -> int:
+    if n < 2 or n & (n - 1):
+        raise ValueError("length must be a power of two >= 2")
+    return n.bit_length() - 1
+
+
+def _cyclic(a, mod, root, convention, inverse, eng):
+    eng = eng or default_engine()
+    h = _arr(a)
+    vecs = h.reshape(-1, h.shape[-1])
+    d = eng.upload(vecs)
+    s = eng.alloc(vecs.size)
+    check(lib.fhe_ntt_cyclic(eng._h, d.ptr, s.ptr, _log2(vecs.shape[1]), vecs.shape[0], mod, root, convention, inverse, None))
+    out = d.download().reshape(h.shape)
+    return out
+
+
+def ntt(a, mod: int, root: int, eng: Optional[Engine] = None) -> List[int]:
+    """``ntt(a, mod, root)`` of motivation/ntt.py:8-32 (``root`` generates Z_mod*)."""
+    return [int(x) for x in _cyclic(a, mod, root, 0, 0, eng)]
+
+
+def intt(a, mod: int, root: int, eng: Optional[Engine] = None) -> List[int]:
+    """``intt(a, mod, root)`` of motivation/bsgs.py:31-36."""
+    return [int(x) for x in _cyclic(a, mod, root, 0, 1, eng)]
+
+
+def ntt_nthroot(a, root: int, mod: int, eng: Optional[Engine] = None) -> List[int]:
+    """``ntt(a, root, mod)`` of rfhe_framewk/src/negaclic_ntt.py:38-57 (``root`` is an n-th root)."""
+    return [int(x) for x in _cyclic(a, mod, root, 1, 0, eng)]
+
+
+def intt_nthroot(a, root: int, mod: int, eng: Optional[Engine] = None) -> List[int]:
+    """``intt(a, root, mod)`` of rfhe_framewk/src/negaclic_ntt.py:77-83."""
+    return [int(x) for x in _cyclic(a, mod, root, 1, 1, eng)]
+
+
+def _psi_tables(eng: Engine, n: int, psi: int, mod: int) -> NttTables:
+    log_n = _log2(n)
+    rp = np.zeros(n, dtype=_U64)
+    p = 1
+    for i in range(n):
+        rp[int(f"{i:0{log_n}b}"[::-1], 2)] = p
+        p = p * psi % mod
+    return eng.tables_from_roots(log_n, [mod], rp)
+
+
+def negacyclic_ntt(a, psi: int, mod: int, eng: Optional[Engine] = None) -> List[int]:
+    """``negacyclic_ntt(a, psi, mod)`` of rfhe_framewk/src/negaclic_ntt.py:86-92 (natural-order output)."""
+    eng = eng or default_engine()
+    n = len(a)
+    t = _psi_tables(eng, n, psi, mod)
+    d = eng.upload(a)
+    t.forward(d)
+    out = eng.alloc(n)
+    check(lib.fhe_bitrev_permute(eng._h, out.ptr, d.ptr, t.log_n, 1, None))
+    return [int(x) for x in out.download()]
+
+
+def negacyclic_intt(A, psi: int, mod: int, eng: Optional[Engine] = None) -> List[int]:
+    """``negacyclic_intt(A, psi, mod)`` of rfhe_framewk/src/negaclic_ntt.py:102-109."""
+    eng = eng or default_engine()
+    n = len(A)
+    t = _psi_tables(eng, n, psi, mod)
+    src = eng.upload(A)
+    d = eng.alloc(n)
+    check(lib.fhe_bitrev_permute(eng._h, d.ptr, src.ptr, t.log_n, 1, None))
+    t.inverse(d)
+    return [int(x) for x in d.download()]
+
+
+def poly_mul_negacyclic_ntt(a, b, psi: int, mod: int, eng: Optional[Engine] = None) -> List[int]:
+    """``poly_mul_negacyclic_ntt`` of rfhe_framewk/src/negaclic_ntt.py:123-127."""
+    eng = eng or default_engine()
+    t = _psi_tables(eng, len(a), psi, mod)
+    da, db = eng.upload(a), eng.upload(b)
+    t.polymul(da, da, db)
+    return [int(x) for x in da.download()]
+
+
+def four_step_ntt(a, N: int, mod: int = 998244353, g: int = 3, n1: Optional[int] = None, eng: Optional[Engine] = None) -> List[int]:
+    """``four_step_ntt(a, N, mod, g)`` of reliability_test/four_step_ntt_prot.py:71-109.
+    ``n1`` defaults to sqrt(N) as in the reference (:73-75); any power-of-two split is accepted."""
+    eng = eng or default_engine()
+    log_n = _log2(N)
+    if n1 is None:
+        n1 = 1 << (log_n // 2)
+        if n1 * n1 != N:
+            raise AssertionError("N must be a perfect square unless n1 is given")  # four_step_ntt_prot.py:74
+    n2 = N // n1
+    h = vp()
+    check(lib.fhe_fourstep_create(eng._h, n1, n2, mod, g, C.byref(h)))
+    try:
+        src = eng.upload(a)
+        dst = eng.alloc(N)
+        check(lib.fhe_fourstep_ntt(eng._h, dst.ptr, src.ptr, h, None))
+        return [int(x) for x in dst.download()]
+    finally:
+        lib.fhe_fourstep_destroy(h)
+
+
+class BaseConv:
+    """Base-conversion plan for (moduli_in -> moduli_out)."""
+
+    def __init__(self, eng: Engine, moduli_in: Sequence[int], moduli_out: Sequence[int]):
+        self.eng, self.m, self.k = eng, len(moduli_in), len(moduli_out)
+        mi, mo = _arr(moduli_in), _arr(moduli_out)
+        h = vp()
+        check(lib.fhe_baseconv_create(eng._h, _ptr(mi), self.m, _ptr(mo), self.k, C.byref(h)))
+        self._h = h
+
+    def exact(self, out: DeviceArray, inp: DeviceArray, N: int, stream=None):
+        check(lib.fhe_baseconv_exact(self.eng._h, out.ptr, inp.ptr, self._h, N, stream))
+
+    def fast(self, out: DeviceArray, inp: DeviceArray, N: int, stream=None):
+        check(lib.fhe_baseconv_fast(self.eng._h, out.ptr, inp.ptr, self._h, N, stream))
+
+    def __del__(self):
+        try:
+            if self._h and self.eng._h:
+                lib.fhe_baseconv_destroy(self._h)
+        except Exception:
+            pass
+
+
+def base_conv_fixed(residue_arrays, moduli_in, moduli_out, eng: Optional[Engine] = None) -> List[List[int]]:
+    """``base_conv_fixed`` of motivation/baseConv.py:67-83; returns ``[k][i]``."""
+    eng = eng or default_engine()
+    r = _arr(residue_arrays)
+    N = r.shape[1]
+    bc = BaseConv(eng, moduli_in, moduli_out)
+    d = eng.upload(r)
+    o = eng.alloc(len(moduli_out) * N)
+    bc.exact(o, d, N)
+    return o.download().reshape(len(moduli_out), N).tolist()
+
+
+def bConv(residue_arrays, moduli, moduli_out, eng: Optional[Engine] = None) -> List[List[int]]:
+    """``bConv`` of rfhe_framewk/src/baseConv.py:10-40; returns ``[i][k]`` like the reference."""
+    eng = eng or default_engine()
+    r = _arr(residue_arrays)
+    N = r.shape[1]
+    bc = BaseConv(eng, moduli, moduli_out)
+    d = eng.upload(r)
+    o = eng.alloc(len(moduli_out) * N)
+    bc.fast(o, d, N)
+    return o.download().reshape(len(moduli_out), N).T.tolist()
+
+
+def crt_garner(residues, moduli, eng: Optional[Engine] = None):
+    """``crt_kernel`` of rfhe_framewk/src/baseConv.cu:85-120; returns (x_lo, x_hi) arrays."""
+    eng = eng or default_engine()
+    r = _arr(residues)
+    m, N = r.shape
+    mod = _arr(moduli)
+    d = eng.upload(r)
+    lo, hi = eng.alloc(N), eng.alloc(N)
+    check(lib.fhe_crt_garner(eng._h, lo.ptr, hi.ptr, d.ptr, _ptr(mod), m, N, None))
+    return lo.download(), hi.download()
+
+
+def diag_block_hadamard_matvec(M_blocks, v, mod: int = 0, eng: Optional[Engine] = None) -> np.ndarray:
+    """``diag_block_hadamard_matvec`` of motivation/bsgs.py:39-52 (``mod=0``: the reference's
+    unreduced int64 arithmetic)."""
+    eng = eng or default_engine()
+    M = np.ascontiguousarray(np.asarray(M_blocks, dtype=np.int64)).view(_U64)
+    vv = np.ascontiguousarray(np.asarray(v, dtype=np.int64)).view(_U64)
+    k, bs = M.shape
+    dM, dv = eng.upload(M), eng.upload(vv)
+    y = eng.alloc(k * bs)
+    check(lib.fhe_bsgs_hadamard(eng._h, y.ptr, dM.ptr, dv.ptr, k, bs, mod, None))
+    out = y.download()
+    return out.view(np.int64) if mod == 0 else out

@@ -1,0 +1,179 @@
+/*
+ * fhe_mi355x.h -- C ABI of libfhe_mi355x.so, the MI355X (gfx950) negacyclic-NTT /
+ * RNS polynomial-arithmetic engine.
+ *
+ * Plain C: opaque handles, raw device addresses, sizes; every function returns an
+ * int status (0 = FHE_OK) and never throws across the boundary; fhe_last_error()
+ * gives the text of the last failure on the calling thread.  All work is enqueued
+ * on the stream passed in (a hipStream_t as void*; NULL = the context's own
+ * stream); the caller synchronises (fhe_sync), exactly as the reference's harness
+ * does around the Phantom calls (reliability_test/ntt_test.cu:88-102).
+ *
+ * Each entry point cites the reference interface it stands in for.  Paths are
+ * relative to the Stardust-lf/fhe-reliability-gpu tree.  "Phantom" symbols are the
+ * ones the reference's binaries import from the (absent) libPhantom.so
+ * (nm -D reliability_test/build/ntt_test).
+ *
+ * Data layout: residue polynomials are limb-major, [n_poly][limbs][N] uint64_t,
+ * contiguous (h_data[i*dim + j], reliability_test/ntt_test.cu:79).
+ * Semantics: every 64-bit input word is first taken modulo its limb's modulus, all
+ * outputs are canonical residues in [0, q).
+ */
+#ifndef FHE_MI355X_H
+#define FHE_MI355X_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define FHE_OK 0
+#define FHE_ERR_INVALID 1     /* bad argument */
+#define FHE_ERR_HIP 2         /* HIP runtime error, see fhe_last_error() */
+#define FHE_ERR_UNSUPPORTED 3 /* size / modulus outside what the kernels handle */
+#define FHE_ERR_NOMEM 4
+
+#define FHE_PATH_F64 0 /* q < 2^50: exact FP64 arithmetic (reference prime size, ntt_test.cu:44) */
+#define FHE_PATH_U64 1 /* q < 2^61: 64-bit Shoup / Harvey arithmetic */
+
+typedef struct fhe_ctx fhe_ctx;               /* device + stream (phantom::util::cuda_stream_wrapper, ntt_test.cu:40-41) */
+typedef struct fhe_ntt_tables fhe_ntt_tables; /* DModulus[] + DNTTTable (ntt_test.cu:47-69) */
+typedef struct fhe_baseconv fhe_baseconv;     /* base-conversion plan (rfhe_framewk/src/baseConv.py:14-18) */
+typedef struct fhe_fourstep fhe_fourstep;     /* four-step plan (reliability_test/four_step_ntt_prot.py:71-79) */
+
+int fhe_version(void);
+const char *fhe_last_error(void);
+
+/* ---- context, memory, streams ------------------------------------------- */
+/* cuda_stream_wrapper{ctor,get_stream} (ntt_test.cu:40-41).  device = HIP ordinal. */
+int fhe_ctx_create(int device, fhe_ctx **out);
+int fhe_ctx_destroy(fhe_ctx *ctx);
+int fhe_ctx_stream(fhe_ctx *ctx, void **stream_out);
+/* cudaStreamSynchronize (ntt_test.cu:102,151) */
+int fhe_sync(fhe_ctx *ctx, void *stream);
+/* make_cuda_auto_ptr<uint64_t>(n, stream) / its destructor (ntt_test.cu:88) */
+int fhe_alloc(fhe_ctx *ctx, size_t bytes, void **dptr);
+int fhe_free(fhe_ctx *ctx, void *dptr);
+/* cudaMemcpyAsync H2D / D2H / D2D (ntt_test.cu:89-101) */
+int fhe_h2d(fhe_ctx *ctx, void *dst, const void *src, size_t bytes, void *stream);
+int fhe_d2h(fhe_ctx *ctx, void *dst, const void *src, size_t bytes, void *stream);
+int fhe_d2d(fhe_ctx *ctx, void *dst, const void *src, size_t bytes, void *stream);
+int fhe_memset(fhe_ctx *ctx, void *dst, int byte, size_t bytes, void *stream);
+
+/* ---- moduli and host tables (a10) ---------------------------------------- */
+/* phantom::arith::CoeffModulus::Create(N, {bits...}) (ntt_test.cu:44): for each bit
+ * size the largest primes p < 2^bits with p = 1 mod 2N, handed out smallest first. */
+int fhe_moduli_create(uint64_t N, const int *bits, int count, uint64_t *out_q);
+/* Modulus::const_ratio() (ntt_test.cu:51-52): out = {floor(2^128/q) lo, hi, 2^128 mod q} */
+int fhe_modulus_const_ratio(uint64_t q, uint64_t out[3]);
+/* minimal primitive `order`-th root of unity mod q (what phantom::arith::NTT picks) */
+int fhe_min_primitive_root(uint64_t q, uint64_t order, uint64_t *out);
+/* NTT::get_from_root_powers() / get_from_root_powers_shoup() (ntt_test.cu:60-64):
+ * rp[bitrev(i)] = psi^i, shoup[k] = floor(rp[k] 2^64 / q); either pointer may be NULL */
+int fhe_root_powers(uint64_t q, int log_n, uint64_t *rp, uint64_t *rp_shoup);
+
+/* ---- NTT tables (device) -------------------------------------------------- */
+/* DModulus::set + DNTTTable::init/set for `count` limbs (ntt_test.cu:47-69) with the
+ * tables of phantom::arith::NTT(log_n, q[i]).  Limb i uses FHE_PATH_F64 when
+ * q[i] < 2^50, else FHE_PATH_U64 (q[i] < 2^61). */
+int fhe_ntt_tables_create(fhe_ctx *ctx, int log_n, const uint64_t *q, int count, fhe_ntt_tables **out);
+/* Same, from caller-supplied forward root powers (count x N, entry k = psi^bitrev(k)):
+ * the DNTTTable::set(..., twiddle, twiddle_shoup, ...) path of ntt_test.cu:61-69.
+ * force_path: -1 = choose by modulus size, else FHE_PATH_*. */
+int fhe_ntt_tables_create_from_roots(fhe_ctx *ctx, int log_n, const uint64_t *q, int count,
+                                     const uint64_t *root_powers, int force_path, fhe_ntt_tables **out);
+int fhe_ntt_tables_destroy(fhe_ntt_tables *t);
+/* out_path[i] = arithmetic path of limb i; out_psi[i] = its 2N-th root (either may be NULL) */
+int fhe_ntt_tables_info(const fhe_ntt_tables *t, int *log_n, int *count, int *out_path, uint64_t *out_psi);
+
+/* ---- transforms (a2, a3) --------------------------------------------------- */
+/* nwt_2d_radix8_forward_inplace(uint64_t*, const DNTTTable&, size_t coeff_modulus_size,
+ * size_t start_modulus_idx, const cudaStream_t&) (ntt_test.cu:95,144; ntt_real_test.cu:89,126):
+ * `limbs` forward negacyclic NTTs in place, limb i with modulus start_idx + i;
+ * natural-order input, bit-reversed output, results in [0,q). */
+int fhe_ntt_forward_inplace(fhe_ctx *ctx, uint64_t *d_data, const fhe_ntt_tables *t, size_t limbs, size_t start_idx,
+                            void *stream);
+/* Phantom's inverse (nwt_2d_radix8_backward_inplace, used inside multiply/decrypt,
+ * reliability_test/dotprod_test.cu:113,119): bit-reversed input, natural output, times N^-1;
+ * equals rfhe_framewk/src/negaclic_ntt.py:102-109 composed with the bit reversal. */
+int fhe_ntt_inverse_inplace(fhe_ctx *ctx, uint64_t *d_data, const fhe_ntt_tables *t, size_t limbs, size_t start_idx,
+                            void *stream);
+/* Batched forms: d_data = [n_poly][limbs][N]; polynomial p, limb i uses modulus start_idx + i. */
+int fhe_ntt_forward_batch(fhe_ctx *ctx, uint64_t *d_data, const fhe_ntt_tables *t, size_t n_poly, size_t limbs,
+                          size_t start_idx, void *stream);
+int fhe_ntt_inverse_batch(fhe_ctx *ctx, uint64_t *d_data, const fhe_ntt_tables *t, size_t n_poly, size_t limbs,
+                          size_t start_idx, void *stream);
+
+/* d_dst[v][i] = d_src[v][bitrev(i, log_n)] for n_vec vectors; d_dst != d_src.  Converts between
+ * the bit-reversed order of the Phantom-style transforms and the natural order the
+ * reference's Python returns (rfhe_framewk/src/negaclic_ntt.py:16-21,42). */
+int fhe_bitrev_permute(fhe_ctx *ctx, uint64_t *d_dst, const uint64_t *d_src, int log_n, size_t n_vec, void *stream);
+
+/* ---- cyclic transform (a1) --------------------------------------------------- */
+/* ntt(a, mod, root) of motivation/ntt.py:8-32 (twins motivation/bsgs.py:5-29,
+ * rfhe_framewk/src/ntt.py:38-55): natural order in and out, `root` a generator
+ * (wlen = root^((mod-1)/len)); any modulus < 2^61, composite included.
+ * convention 1 selects rfhe_framewk/src/negaclic_ntt.py:38-57 (root is a primitive
+ * n-th root, wlen = root^(n/len)).  inverse != 0 gives intt(): transform with
+ * root^(mod-2), then times n^(mod-2) (motivation/bsgs.py:31-36).
+ * d_data: n_vec vectors of 2^log_n words, in place; d_scratch: same size. */
+int fhe_ntt_cyclic(fhe_ctx *ctx, uint64_t *d_data, uint64_t *d_scratch, int log_n, size_t n_vec, uint64_t mod,
+                   uint64_t root, int convention, int inverse, void *stream);
+
+/* ---- four-step transform (a6) -------------------------------------------------- */
+/* four_step_ntt(a, N) of reliability_test/four_step_ntt_prot.py:71-109 with N = n1*n2
+ * (both powers of two, n1 != n2 allowed): column transforms, twiddle w^(k2 t1), row
+ * transforms, transposed output; equals ntt_direct (:49-58).  g = generator (G=3, :17). */
+int fhe_fourstep_create(fhe_ctx *ctx, uint64_t n1, uint64_t n2, uint64_t mod, uint64_t g, fhe_fourstep **out);
+int fhe_fourstep_destroy(fhe_fourstep *p);
+int fhe_fourstep_ntt(fhe_ctx *ctx, uint64_t *d_dst, const uint64_t *d_src, fhe_fourstep *p, void *stream);
+
+/* ---- coefficient-wise products (a4, a5) ------------------------------------------ */
+/* C_hat[i] = A_hat[i] * B_hat[i] % mod (rfhe_framewk/src/negaclic_ntt.py:126), per limb;
+ * the NTT-domain core of phantom::multiply (dotprod_test.cu:113).  c may alias a or b. */
+int fhe_modmul(fhe_ctx *ctx, uint64_t *d_c, const uint64_t *d_a, const uint64_t *d_b, const fhe_ntt_tables *t,
+               size_t n_poly, size_t limbs, size_t start_idx, void *stream);
+/* c = (c + a*b) mod q: keyswitch / BSGS inner-product accumulate (motivation/bsgs.py:50) */
+int fhe_modmul_acc(fhe_ctx *ctx, uint64_t *d_c, const uint64_t *d_a, const uint64_t *d_b, const fhe_ntt_tables *t,
+                   size_t n_poly, size_t limbs, size_t start_idx, void *stream);
+/* poly_mul_negacyclic_ntt (rfhe_framewk/src/negaclic_ntt.py:123-127): c = a * b mod (x^N + 1, q).
+ * a and b are overwritten with their transforms (as the NTT-domain ciphertexts of the
+ * reference stay transformed); c may alias a. */
+int fhe_polymul(fhe_ctx *ctx, uint64_t *d_c, uint64_t *d_a, uint64_t *d_b, const fhe_ntt_tables *t, size_t n_poly,
+                size_t limbs, size_t start_idx, void *stream);
+
+/* ---- base conversion / CRT (a8) ------------------------------------------------- */
+int fhe_baseconv_create(fhe_ctx *ctx, const uint64_t *mod_in, int m, const uint64_t *mod_out, int k,
+                        fhe_baseconv **out);
+int fhe_baseconv_destroy(fhe_baseconv *p);
+/* base_conv_fixed (motivation/baseConv.py:67-83): exact; in m x N, out k x N (limb-major) */
+int fhe_baseconv_exact(fhe_ctx *ctx, uint64_t *d_out, const uint64_t *d_in, const fhe_baseconv *p, size_t N,
+                       void *stream);
+/* bConv (rfhe_framewk/src/baseConv.py:10-40): sum_j ((r_j Phat_j inv_j) mod q_k), NOT reduced;
+ * out k x N limb-major (the reference returns the transposed [i][k] list).  Requires
+ * m * max(q_k) < 2^64. */
+int fhe_baseconv_fast(fhe_ctx *ctx, uint64_t *d_out, const uint64_t *d_in, const fhe_baseconv *p, size_t N,
+                      void *stream);
+/* crt_kernel (rfhe_framewk/src/baseConv.cu:85-120, launch :187-193): Garner CRT of m <= 16
+ * limbs into a 128-bit integer (lo, hi) per coefficient, 128-bit wrap-around as the
+ * kernel; residues m x N row-major. */
+int fhe_crt_garner(fhe_ctx *ctx, uint64_t *d_x_lo, uint64_t *d_x_hi, const uint64_t *d_residues,
+                   const uint64_t *moduli, int m, size_t N, void *stream);
+
+/* ---- BSGS block-diagonal Hadamard (a9) --------------------------------------------- */
+/* diag_block_hadamard_matvec (motivation/bsgs.py:39-52): y_i = sum_j M[(j-i) mod k] (.) v_j,
+ * k blocks of `block_size`.  mod == 0: int64 wrap-around, no reduction (the reference's
+ * NumPy arithmetic); otherwise every product and the sum are reduced mod `mod`. */
+int fhe_bsgs_hadamard(fhe_ctx *ctx, uint64_t *d_y, const uint64_t *d_M_blocks, const uint64_t *d_v, int k,
+                      int block_size, uint64_t mod, void *stream);
+
+/* ---- fault injection ---------------------------------------------------------------- */
+/* _flip_bit_kernel<<<1,1>>> (reliability_test/dotprod_test.cu:31-33,55): data[idx] ^= 1 << bit */
+int fhe_flip_bit(fhe_ctx *ctx, uint64_t *d_data, uint64_t idx, int bit, void *stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* FHE_MI355X_H */

@@ -1,0 +1,129 @@
+// emu_ntt.cpp -- CPU emulation of the HIP NTT passes (TEST INFRASTRUCTURE ONLY).
+//
+// Compiles fhe_reliability_gpu_amd/csrc/ntt_core.hpp / ntt_plan.hpp with g++ and
+// runs every workgroup step as a loop over thread ids, so the tile indexing, the
+// twiddle indexing, the LDS exchange pattern and the FP64 lazy-range schedule can be
+// checked against the oracle without a GPU.  It is NOT a product path: the library
+// never links this file.
+//
+//   g++ -O2 -std=c++17 -ffp-contract=off -shared -fPIC -I<csrc> emu_ntt.cpp -o libemu_ntt.so
+#include "ntt_plan.hpp"
+
+#include <cmath>
+#include <vector>
+
+using namespace fhe;
+
+namespace {
+
+// largest |value| (in units of q) any FP64 register held, to validate the lazy schedule
+double g_max_ratio = 0.0;
+
+template <class PASS, int LOGN, bool INV, bool IS_COL>
+void emu_pass(const PassArgs &a)
+{
+    typedef typename PASS::Arith A;
+    const u32 blocks = a.units * PASS::TILES;
+    std::vector<typename PASS::elem> lds(PASS::LDS_ELEMS > 0 ? PASS::LDS_ELEMS : 1);
+    for (u32 b = 0; b < blocks; b++) {
+        u32 limb, row0 = 0;
+        u64 *base;
+        if constexpr (IS_COL) base = col_tile<PASS, LOGN>(b, a, limb);
+        else base = row_tile<PASS, LOGN>(b, a, limb, row0);
+        const LimbParams &p = a.lp[limb];
+        auto ctx = A::make_ctx(p);
+        const Tw *tw = INV ? p.inv : p.fwd;
+        for (int tid = 0; tid < NTT_THREADS; tid++) PASS::template step<0>(tid, base, lds.data(), tw, row0, ctx, p.inv_n);
+        if constexpr (PASS::NSTEP > 1)
+            for (int tid = 0; tid < NTT_THREADS; tid++) PASS::template step<1>(tid, base, lds.data(), tw, row0, ctx, p.inv_n);
+        if constexpr (PASS::NSTEP > 2)
+            for (int tid = 0; tid < NTT_THREADS; tid++) PASS::template step<2>(tid, base, lds.data(), tw, row0, ctx, p.inv_n);
+        if constexpr (A::PATH == PATH_F64) {
+            for (auto v : lds) {
+                double r = std::fabs((double)v) / p.n;
+                if (r > g_max_ratio) g_max_ratio = r;
+            }
+        }
+    }
+}
+
+template <class A, int LOGN, bool INV>
+void emu_transform(const PassArgs &a)
+{
+    typedef Passes<A, LOGN, INV> PS;
+    if constexpr (!PS::G::TWO_PASS) {
+        emu_pass<typename PS::Single, LOGN, INV, false>(a);
+    } else if constexpr (!INV) {
+        emu_pass<typename PS::Col, LOGN, INV, true>(a);
+        emu_pass<typename PS::Row, LOGN, INV, false>(a);
+    } else {
+        emu_pass<typename PS::Row, LOGN, INV, false>(a);
+        emu_pass<typename PS::Col, LOGN, INV, true>(a);
+    }
+}
+
+template <class A, int LOGN>
+void emu_dir(const PassArgs &a, int inverse)
+{
+    if (inverse) emu_transform<A, LOGN, true>(a);
+    else emu_transform<A, LOGN, false>(a);
+}
+
+template <class A>
+int emu_size(const PassArgs &a, int logn, int inverse)
+{
+    switch (logn) {
+#define CASE(L) case L: emu_dir<A, L>(a, inverse); return 0;
+        CASE(1) CASE(2) CASE(3) CASE(4) CASE(5) CASE(6) CASE(7) CASE(8) CASE(9) CASE(10)
+        CASE(11) CASE(12) CASE(13) CASE(14) CASE(15) CASE(16) CASE(17) CASE(18)
+#undef CASE
+    default: return -1;
+    }
+}
+
+u64 invmod(u64 a, u64 m)
+{
+    __int128 t = 0, nt = 1, r = m, nr = a % m;
+    while (nr != 0) {
+        __int128 q = r / nr, tmp;
+        tmp = t - q * nt; t = nt; nt = tmp;
+        tmp = r - q * nr; r = nr; nr = tmp;
+    }
+    if (t < 0) t += m;
+    return (u64)t;
+}
+
+} // namespace
+
+// data: [n_poly][limbs][N] in place.  q: limbs moduli.  rp: limbs x N forward tables
+// (canonical residues, entry k = psi^bitrev(k)).  path: 0 = ArithF64, 1 = ArithU64.
+extern "C" int emu_ntt(u64 *data, int logn, int inverse, int n_poly, int limbs, const u64 *q, const u64 *rp, int path)
+{
+    const size_t N = (size_t)1 << logn;
+    std::vector<LimbParams> lp(limbs);
+    std::vector<std::vector<Tw>> fwd(limbs), inv(limbs);
+    for (int l = 0; l < limbs; l++) {
+        fwd[l].resize(N);
+        inv[l].resize(N);
+        for (size_t k = 0; k < N; k++) {
+            u64 w = rp[(size_t)l * N + k], wi = invmod(w, q[l]);
+            fwd[l][k] = path == PATH_F64 ? ArithF64::encode(w, q[l]) : ArithU64::encode(w, q[l]);
+            inv[l][k] = path == PATH_F64 ? ArithF64::encode(wi, q[l]) : ArithU64::encode(wi, q[l]);
+        }
+        LimbParams &p = lp[l];
+        p.q = q[l];
+        p.two_q = 2 * q[l];
+        p.n = (double)q[l];
+        p.ninv = 1.0 / p.n;
+        u64 ni = invmod(N % q[l], q[l]);
+        p.inv_n = path == PATH_F64 ? ArithF64::encode(ni, q[l]) : ArithU64::encode(ni, q[l]);
+        p.fwd = fwd[l].data();
+        p.inv = inv[l].data();
+        p.path = path;
+    }
+    PassArgs a{data, lp.data(), 0u, (u32)limbs, (u32)(n_poly * limbs), (u32)limbs};
+    g_max_ratio = 0.0;
+    return path == PATH_F64 ? emu_size<ArithF64>(a, logn, inverse) : emu_size<ArithU64>(a, logn, inverse);
+}
+
+extern "C" double emu_max_ratio() { return g_max_ratio; }

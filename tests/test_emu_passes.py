@@ -1,0 +1,91 @@
+"""CPU emulation of the HIP NTT passes (tests/emu/emu_ntt.cpp compiles the very same
+template code the kernels instantiate) against the oracle: checks tile/twiddle
+indexing, the LDS exchange addressing and the FP64 lazy-range schedule for every
+supported size, without a GPU."""
+import ctypes as C
+import os
+import subprocess
+
+import numpy as np
+import pytest
+
+from oracle import cport as O
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+EMU_DIR = os.path.join(ROOT, "tests", "emu")
+CSRC = os.path.join(ROOT, "fhe_reliability_gpu_amd", "csrc")
+p64 = C.POINTER(C.c_uint64)
+
+
+@pytest.fixture(scope="module")
+def emu():
+    so = os.path.join(EMU_DIR, "libemu_ntt.so")
+    srcs = [os.path.join(EMU_DIR, "emu_ntt.cpp")] + [os.path.join(CSRC, f) for f in ("modarith.hpp", "ntt_core.hpp", "ntt_plan.hpp")]
+    if not os.path.exists(so) or os.path.getmtime(so) < max(os.path.getmtime(s) for s in srcs):
+        subprocess.check_call(["g++", "-O2", "-std=c++17", "-ffp-contract=off", "-shared", "-fPIC", "-I" + CSRC,
+                               srcs[0], "-o", so])
+    L = C.CDLL(so)
+    L.emu_ntt.restype = C.c_int
+    L.emu_ntt.argtypes = [p64, C.c_int, C.c_int, C.c_int, C.c_int, p64, p64, C.c_int]
+    L.emu_max_ratio.restype = C.c_double
+    return L
+
+
+def _run(emu, data, logn, inverse, qs, rps, path):
+    d = np.ascontiguousarray(data, dtype=np.uint64).copy()
+    n_poly, limbs, _ = d.shape
+    q = np.asarray(qs, dtype=np.uint64)
+    rp = np.ascontiguousarray(rps, dtype=np.uint64)
+    rc = emu.emu_ntt(d.ctypes.data_as(p64), logn, inverse, n_poly, limbs, q.ctypes.data_as(p64), rp.ctypes.data_as(p64), path)
+    assert rc == 0
+    return d
+
+
+def _tables(logn, bits, limbs):
+    N = 1 << logn
+    qs = O.gen_primes(max(N, 2), bits, limbs)
+    rps = np.stack([O.root_powers(q, logn) for q in qs])
+    return qs, rps
+
+
+@pytest.mark.parametrize("logn", list(range(1, 18)))
+@pytest.mark.parametrize("path,bits", [(0, 50), (1, 61), (1, 50), (0, 30)])
+def test_emulated_passes_match_oracle(emu, logn, path, bits):
+    if logn >= 15 and (path, bits) in ((1, 50), (0, 30)):
+        pytest.skip("covered by the smaller sizes")
+    limbs = 2 if logn <= 14 else 1
+    n_poly = 2 if logn <= 12 else 1
+    N = 1 << logn
+    qs, rps = _tables(logn, bits, limbs)
+    rng = np.random.default_rng(logn * 10 + path)
+    data = np.stack([np.stack([rng.integers(0, q, N, dtype=np.uint64) for q in qs]) for _ in range(n_poly)])
+    # worst-case-ish inputs for the lazy ranges: all q-1 in one polynomial
+    data[0, 0, :] = qs[0] - 1
+    fwd = _run(emu, data, logn, 0, qs, rps, path)
+    if path == 0:
+        assert emu.emu_max_ratio() < 8.0
+    for p in range(n_poly):
+        for l in range(limbs):
+            want = O.nwt_forward(data[p, l], qs[l], rps[l])
+            assert (fwd[p, l] == want).all(), f"forward mismatch poly {p} limb {l}"
+    back = _run(emu, fwd, logn, 1, qs, rps, path)
+    if path == 0:
+        assert emu.emu_max_ratio() < 8.0
+    assert (back == data).all()
+
+
+@pytest.mark.parametrize("path", [0, 1])
+def test_out_of_range_words_are_reduced_first(emu, path):
+    # bit-flipped symbols (reliability_test/ntt_test.cu:104-135) may exceed q
+    logn, N = 10, 1024
+    qs, rps = _tables(logn, 50, 1)
+    rng = np.random.default_rng(7)
+    data = rng.integers(0, qs[0], (1, 1, N), dtype=np.uint64)
+    data[0, 0, 5] ^= np.uint64(1 << 63)
+    data[0, 0, 17] ^= np.uint64(1 << 51)
+    data[0, 0, 99] = np.uint64(qs[0])          # == q
+    data[0, 0, 100] = np.uint64(2**64 - 1)
+    fwd = _run(emu, data, logn, 0, qs, rps, path)
+    assert (fwd[0, 0] == O.nwt_forward(data[0, 0], qs[0], rps[0])).all()
+    inv = _run(emu, data, logn, 1, qs, rps, path)
+    assert (inv[0, 0] == O.nwt_inverse(data[0, 0], qs[0], rps[0])).all()

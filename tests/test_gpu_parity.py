@@ -1,0 +1,343 @@
+"""Parity of the HIP path (through the C ABI) against the CPU oracle and the golden
+vectors generated from the reference's Python.  Bit-exact: every comparison is ==.
+Run on the MI355X box with ``pytest -m gpu``."""
+import hashlib
+import random
+
+import numpy as np
+import pytest
+
+from conftest import load_golden, sha_u64
+
+pytestmark = pytest.mark.gpu
+
+Q61 = 2305843009211596801
+PHANTOM_PRIMES = [1125899903107073, 1125899903500289, 1125899903795201,
+                  1125899903827969, 1125899903991809, 1125899904679937]
+
+
+@pytest.fixture(scope="module")
+def F():
+    import fhe_reliability_gpu_amd as f
+    return f
+
+
+@pytest.fixture(scope="module")
+def eng(F):
+    return F.default_engine()
+
+
+@pytest.fixture(scope="module")
+def O():
+    from oracle import cport
+    return cport
+
+
+def _rand_limbs(rng, qs, N, n_poly=1):
+    return np.stack([np.stack([rng.integers(0, q, N, dtype=np.uint64) for q in qs]) for _ in range(n_poly)])
+
+
+# ------------------------------------------------------------------ a2 / a3
+@pytest.mark.parametrize("logn", list(range(1, 19)))
+@pytest.mark.parametrize("bits", [50, 61, 30])
+def test_forward_inverse_match_oracle(F, eng, O, logn, bits):
+    if bits == 30 and logn > 14:
+        pytest.skip("small-modulus FP64 case covered at the smaller sizes")
+    N = 1 << logn
+    limbs = 3 if logn <= 14 else (2 if logn <= 16 else 1)
+    n_poly = 2 if logn <= 13 else 1
+    qs = F.create_moduli(N, [bits] * limbs)
+    assert qs == O.gen_primes(N, bits, limbs)            # a10: same primes as the oracle's rule
+    t = eng.tables(logn, qs)
+    assert t.paths == [0 if bits <= 50 else 1] * limbs
+    assert t.psi == [O.min_primitive_root(q, 2 * N) for q in qs]
+    rps = [O.root_powers(q, logn) for q in qs]
+    rng = np.random.default_rng(1000 * logn + bits)
+    data = _rand_limbs(rng, qs, N, n_poly)
+    data[0, 0, :] = qs[0] - 1                            # extreme values for the lazy ranges
+    d = eng.upload(data)
+    t.forward(d, n_poly=n_poly)
+    fwd = d.download()
+    for p in range(n_poly):
+        for l in range(limbs):
+            assert (fwd[p, l] == O.nwt_forward(data[p, l], qs[l], rps[l])).all(), (p, l)
+    t.inverse(d, n_poly=n_poly)
+    assert (d.download() == data).all()
+    # inverse on its own input (not a round trip)
+    d2 = eng.upload(data)
+    t.inverse(d2, n_poly=n_poly)
+    inv = d2.download()
+    for l in range(limbs):
+        assert (inv[0, l] == O.nwt_inverse(data[0, l], qs[l], rps[l])).all()
+
+
+def test_kat2_phantom_prime_ring(F, eng):
+    # the dotprod_test ring, first logged Phantom prime
+    q, logn = PHANTOM_PRIMES[0], 14
+    t = eng.tables(logn, [q])
+    assert t.psi == [32853495844]
+    a = np.array([(i * i + 1) % q for i in range(1 << logn)], dtype=np.uint64)
+    d = eng.upload(a)
+    t.forward(d)
+    out = d.download()
+    assert [int(x) for x in out[:4]] == [1037891225979181, 928784233542420, 626683383818997, 933202470215772]
+    assert sha_u64(out) == "79d3fd044499dd0c43406c0e0d282a73b2aba27be4fdb7efba6342e00d9a3a4d"
+
+
+def test_mixed_paths_and_limb_window(F, eng, O):
+    # 50-bit and 61-bit limbs in one table set, transformed through a start_idx window
+    logn, N = 12, 4096
+    qs = F.create_moduli(N, [50, 61, 50, 50, 61, 61])
+    t = eng.tables(logn, qs)
+    assert t.paths == [0, 1, 0, 0, 1, 1]
+    rng = np.random.default_rng(5)
+    start, limbs, n_poly = 1, 4, 3
+    data = _rand_limbs(rng, qs[start:start + limbs], N, n_poly)
+    d = eng.upload(data)
+    t.forward(d, limbs=limbs, start=start, n_poly=n_poly)
+    got = d.download()
+    for p in range(n_poly):
+        for l in range(limbs):
+            q = qs[start + l]
+            assert (got[p, l] == O.nwt_forward(data[p, l], q, O.root_powers(q, logn))).all()
+    t.inverse(d, limbs=limbs, start=start, n_poly=n_poly)
+    assert (d.download() == data).all()
+
+
+@pytest.mark.parametrize("bits", [50, 61])
+def test_out_of_range_words(F, eng, O, bits):
+    # the fault-injection harness flips arbitrary bits (reliability_test/ntt_test.cu:104-135)
+    logn, N = 13, 8192
+    q = F.create_moduli(N, [bits])[0]
+    t = eng.tables(logn, [q])
+    rng = np.random.default_rng(9)
+    a = rng.integers(0, q, N, dtype=np.uint64)
+    a[3] ^= np.uint64(1 << 63)
+    a[77] ^= np.uint64(1 << 52)
+    a[500] = np.uint64(q)
+    a[501] = np.uint64(2**64 - 1)
+    d = eng.upload(a)
+    t.forward(d)
+    assert (d.download() == O.nwt_forward(a, q, O.root_powers(q, logn))).all()
+
+
+def test_tables_from_caller_roots(F, eng, O):
+    # DNTTTable::set with host tables (ntt_test.cu:61-69), forcing each arithmetic path
+    logn, N = 10, 1024
+    q = PHANTOM_PRIMES[1]
+    psi = O.min_primitive_root(q, 2 * N)
+    psi = pow(psi, 3, q)                      # a non-minimal root: still a valid table
+    rp = O.root_powers(q, logn, psi)
+    rng = np.random.default_rng(2)
+    a = rng.integers(0, q, N, dtype=np.uint64)
+    want = O.nwt_forward(a, q, rp)
+    for path in (0, 1):
+        t = eng.tables_from_roots(logn, [q], rp, force_path=path)
+        assert t.paths == [path] and t.psi == [psi]
+        d = eng.upload(a)
+        t.forward(d)
+        assert (d.download() == want).all()
+        t.inverse(d)
+        assert (d.download() == a).all()
+
+
+# ------------------------------------------------------------- golden vectors
+def test_golden_negacyclic_natural_order(F):
+    g = load_golden("negacyclic.json")
+    for case in g["cases"]:
+        n, q, psi = case["n"], case["q"], case["psi"]
+        random.seed(case["seed"])
+        a = [random.randrange(q) for _ in range(n)]
+        fwd = F.negacyclic_ntt(a, psi, q)
+        assert sha_u64(fwd) == case["sha256_fwd"]
+        assert fwd[:8] == case["head"] and fwd[-8:] == case["tail"]
+        assert F.negacyclic_intt(fwd, psi, q) == a
+    for pm in g["polymul"]:
+        assert F.poly_mul_negacyclic_ntt(pm["a"], pm["b"], pm["psi"], pm["q"]) == pm["c"]
+
+
+def test_golden_cyclic(F):
+    g = load_golden("cyclic_ntt.json")
+    d = g["demo"]                              # composite modulus 15728641 (motivation/ntt.py:35-43)
+    assert F.ntt(d["a"], d["mod"], d["root"]) == d["A"]
+    for case in g["cases"]:
+        if case["lg"] < 1:
+            continue
+        random.seed(case["seed"])
+        a = [random.randrange(case["mod"]) for _ in range(1 << case["lg"])]
+        out = F.ntt(a, case["mod"], case["root"])
+        assert sha_u64(out) == case["sha256"]
+        assert out[:8] == case["head"] and out[-8:] == case["tail"]
+    t = g["bsgs_twin"]
+    assert F.ntt(t["a"], t["mod"], t["root"]) == t["fwd"]
+    assert F.intt(t["fwd"], t["mod"], t["root"]) == t["a"]
+    r = g["rfhe_twin"]
+    assert F.ntt(r["a"], r["mod"], r["root"]) == r["fwd"]
+    assert F.intt(r["a"], r["mod"], r["root"]) == r["inv"]
+    r = g["nthroot"]
+    assert F.ntt_nthroot(r["a"], r["root"], r["mod"]) == r["fwd"]
+    assert F.intt_nthroot(r["a"], r["root"], r["mod"]) == r["inv"]
+
+
+def test_golden_four_step(F, O):
+    g = load_golden("four_step.json")
+    for case in g["cases"]:
+        assert F.four_step_ntt(case["a"], case["N"], g["mod"], g["g"]) == case["y"]
+    # n1 != n2 (config 4's 2^17 = 512 x 256 shape, scaled down) equals the direct transform
+    random.seed(3)
+    a = [random.randrange(g["mod"]) for _ in range(2048)]
+    want = [int(x) for x in O.ntt_cyclic(a, g["mod"], g["g"])]
+    assert F.four_step_ntt(a, 2048, g["mod"], g["g"], n1=64) == want
+    assert F.four_step_ntt(a, 2048, g["mod"], g["g"], n1=32) == want
+
+
+def test_four_step_2_16_equals_cyclic(F, O):
+    mod, g, N = 998244353, 3, 1 << 16
+    rng = np.random.default_rng(16)
+    a = rng.integers(0, mod, N, dtype=np.uint64)
+    want = O.ntt_cyclic(a, mod, g)
+    assert (np.array(F.four_step_ntt(a, N, mod, g), dtype=np.uint64) == want).all()
+
+
+def test_golden_base_conversion(F):
+    g = load_golden("baseconv.json")
+    for key in ("exact", "exact50"):
+        e = g[key]
+        assert F.base_conv_fixed(e["res"], e["mod_in"], e["mod_out"]) == e["out"]
+    for key in ("fast", "fast31"):
+        f = g[key]
+        assert F.bConv(f["res"], f["mod_in"], f["mod_out"]) == f["out"]
+
+
+def test_golden_bsgs(F):
+    g = load_golden("bsgs.json")
+    s = g["small"]
+    assert F.diag_block_hadamard_matvec(s["M"], s["v"]).tolist() == s["y"]
+    np.random.seed(g["numpy_seed"])           # motivation/bsgs.py:89-101
+    M = [np.random.randint(0, g["mod"], size=g["block_size"]) for _ in range(g["k"])]
+    v = np.random.randint(0, g["mod"], size=g["block_size"] * g["k"])
+    y = F.diag_block_hadamard_matvec(np.array(M), v)
+    assert y[:32].tolist() == g["y_head"]
+    assert sha_u64(y.astype(np.uint64)) == g["sha256_y"]
+
+
+# ------------------------------------------------------------------- a4 / a5
+def test_modmul_and_accumulate(F, eng, O):
+    logn, N = 12, 4096
+    qs = F.create_moduli(N, [50, 61, 40])
+    t = eng.tables(logn, qs)
+    rng = np.random.default_rng(4)
+    a, b, c = (_rand_limbs(rng, qs, N, 2) for _ in range(3))
+    a[0, 0, :7] = np.uint64(2**64 - 1)         # unreduced operands are reduced first
+    da, db, dc = eng.upload(a), eng.upload(b), eng.upload(c)
+    out = eng.alloc(a.size)
+    out.shape = a.shape
+    t.modmul(out, da, db, n_poly=2)
+    got = out.download()
+    t.modmul(dc, da, db, n_poly=2, acc=True)
+    acc = dc.download()
+    for p in range(2):
+        for l, q in enumerate(qs):
+            assert (got[p, l] == O.modmul(a[p, l], b[p, l], q)).all()
+            assert (acc[p, l] == O.modmul_acc(c[p, l], a[p, l], b[p, l], q)).all()
+
+
+@pytest.mark.parametrize("bits", [50, 61])
+def test_polymul_matches_schoolbook(F, eng, O, bits):
+    logn, N = 8, 256
+    qs = F.create_moduli(N, [bits, bits])
+    t = eng.tables(logn, qs)
+    rng = np.random.default_rng(8)
+    a, b = _rand_limbs(rng, qs, N), _rand_limbs(rng, qs, N)
+    da, db = eng.upload(a), eng.upload(b)
+    t.polymul(da, da, db)
+    got = da.download()
+    for l, q in enumerate(qs):
+        assert (got[0, l] == O.polymul_naive(a[0, l], b[0, l], q)).all()
+
+
+# ----------------------------------------------------------------------- a8
+def test_base_conversion_against_oracle_large(F, eng, O):
+    N = 1 << 12
+    mi = F.create_moduli(N, [50] * 6)
+    mo = F.create_moduli(N, [61] * 3) + [1073741827]
+    rng = np.random.default_rng(12)
+    res = np.stack([rng.integers(0, p, N, dtype=np.uint64) for p in mi])
+    assert (np.array(F.base_conv_fixed(res, mi, mo), dtype=np.uint64) == O.baseconv_exact(res, mi, mo)).all()
+    assert (np.array(F.bConv(res, mi, mo), dtype=np.uint64) == O.bconv_fast(res, mi, mo)).all()
+
+
+def test_crt_garner_matches_oracle(F, O):
+    rng = np.random.default_rng(13)
+    for mod in ([1048583, 1048589, 1048601, 1048609], [1073741827, 1073741831, 1073741833, 1073741839],
+                PHANTOM_PRIMES[:5]):   # the last one exercises the 128-bit wrap-around of the reference kernel
+        N = 1000
+        res = np.stack([rng.integers(0, p, N, dtype=np.uint64) for p in mod])
+        lo, hi = F.crt_garner(res, mod)
+        wlo, whi = O.crt_garner(res, mod)
+        assert (lo == wlo).all() and (hi == whi).all()
+
+
+# ------------------------------------------------------------ fault injection
+def test_flip_bit_and_error_propagation(F, eng):
+    from fhe_reliability_gpu_amd._lib import check, lib
+    # one flipped input symbol corrupts every output of its limb and no other limb
+    # (reliability_test/data/flipimpact_ntt.csv: symbol error rate 1.0; exp_log.txt:3)
+    logn, N, limbs = 12, 4096, 4
+    qs = F.create_moduli(N, [50] * limbs)
+    t = eng.tables(logn, qs)
+    rng = np.random.default_rng(21)
+    data = _rand_limbs(rng, qs, N)
+    d = eng.upload(data)
+    t.forward(d)
+    clean = d.download()
+    d2 = eng.upload(data)
+    check(lib.fhe_flip_bit(eng._h, d2.ptr, 2 * N + 17, 13, None))
+    assert (d2.download().reshape(-1)[2 * N + 17] == (data.reshape(-1)[2 * N + 17] ^ np.uint64(1 << 13)))
+    t.forward(d2)
+    faulty = d2.download()
+    diff = clean != faulty
+    assert diff[0, 2].all() and not diff[0, [0, 1, 3]].any()
+    ber = sum(bin(int(x)).count("1") for x in (clean[0, 2] ^ faulty[0, 2])) / (64 * N)
+    assert 0.36 < ber < 0.42                     # ~25/64 for 50-bit primes (flipimpact_ntt.csv)
+
+
+# ---------------------------------------------------- full-size properties
+@pytest.mark.parametrize("bits", [50, 61])
+def test_full_size_round_trip_and_linearity(F, eng, bits):
+    # BASELINE config 3 shape: N = 2^16, L = 16 limbs; size-independent properties
+    logn, N, L = 16, 1 << 16, 16
+    qs = F.create_moduli(N, [bits] * L)
+    t = eng.tables(logn, qs)
+    rng = np.random.default_rng(33)
+    a, b = _rand_limbs(rng, qs, N), _rand_limbs(rng, qs, N)
+    qcol = np.array(qs, dtype=np.uint64)[None, :, None]
+    s = ((a.astype(object) + b.astype(object)) % qcol.astype(object)).astype(np.uint64)
+    da, db, ds = eng.upload(a), eng.upload(b), eng.upload(s)
+    for x in (da, db, ds):
+        t.forward(x)
+    fa, fb, fs = da.download(), db.download(), ds.download()
+    lin = ((fa.astype(object) + fb.astype(object)) % qcol.astype(object)).astype(np.uint64)
+    assert (fs == lin).all()
+    assert (fa < qcol).all()
+    t.inverse(da)
+    assert (da.download() == a).all()
+    # NTT-domain product == negacyclic product: check x * 1 and x * X (a shift with sign flip)
+    one = np.zeros_like(a)
+    one[:, :, 0] = 1
+    shift = np.zeros_like(a)
+    shift[:, :, 1] = 1
+    dx, d1, dsft = eng.upload(a), eng.upload(one), eng.upload(shift)
+    out = eng.alloc(a.size)
+    out.shape = a.shape
+    t.forward(dx)
+    t.forward(d1)
+    t.forward(dsft)
+    t.modmul(out, dx, d1)
+    t.inverse(out)
+    assert (out.download() == a).all()
+    t.modmul(out, dx, dsft)
+    t.inverse(out)
+    want = np.roll(a, 1, axis=2)
+    want[:, :, 0] = (qcol[:, :, 0] - want[:, :, 0]) % qcol[:, :, 0]
+    assert (out.download() == want).all()
