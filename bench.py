@@ -41,6 +41,7 @@ def main():
     ap.add_argument("--bits", type=int, default=50, help="prime size (50 = reference; 61 = integer path)")
     ap.add_argument("--no-cpu", action="store_true", help="skip the CPU baseline leg")
     ap.add_argument("--check", action="store_true", help="verify one limb against the oracle before timing")
+    ap.add_argument("--mode", choices=["fused", "twopass"], default="twopass")
     args = ap.parse_args()
 
     import torch
@@ -62,6 +63,7 @@ def main():
     from fhe_reliability_gpu_amd._lib import check, lib
 
     eng = F.Engine(local_rank)
+    eng.set_option("ntt_mode", 1 if args.mode == "fused" else 0)
     qs = F.create_moduli(N, [args.bits] * args.limbs)
     tables = eng.tables(LOGN, qs)
     units = args.polys * args.limbs
@@ -73,8 +75,12 @@ def main():
     for l, q in enumerate(qs):
         data[:, l, :] = torch.randint(0, q, (args.polys, N), generator=g, device="cuda", dtype=torch.int64)
     pristine = data.clone()
-    stream = torch.cuda.current_stream()
+    torch.cuda.synchronize()
+    # a non-default torch stream: its handle is non-null, so the library launches on it and
+    # torch.cuda.Event timestamps see the kernels
+    stream = torch.cuda.Stream()
     sptr = C.c_void_p(stream.cuda_stream)
+    assert stream.cuda_stream != 0
     dptr = C.c_void_p(data.data_ptr())
 
     def step():
@@ -84,6 +90,7 @@ def main():
         from oracle import cport as O
         step()
         torch.cuda.synchronize()
+        eng.check()
         got = data[0, 0].cpu().numpy().view(np.uint64)
         want = O.nwt_forward(pristine[0, 0].cpu().numpy().view(np.uint64), qs[0], O.root_powers(qs[0], LOGN))
         assert (got == want).all(), "GPU forward NTT differs from the oracle"
@@ -140,7 +147,8 @@ def main():
         "roofline": {
             "bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
             "traffic": None,
-            "kernel": "two launches per step (column pass + row pass); achieved = 16*N*units bytes / HIP-event time of the step",
+            "kernel": ("k_ntt_fused (one launch per step)" if args.mode == "fused" else "column pass + row pass (two launches per step)")
+                      + "; achieved = 16*N*units bytes / HIP-event time of the step",
             "ms_per_step_device": step_ms_dev,
         },
     }

@@ -43,6 +43,8 @@ _SIG = {
     "fhe_ctx_create": (ci, [ci, C.POINTER(vp)]),
     "fhe_ctx_destroy": (ci, [vp]),
     "fhe_ctx_stream": (ci, [vp, C.POINTER(vp)]),
+    "fhe_ctx_set_option": (ci, [vp, C.c_char_p, C.c_long]),
+    "fhe_ctx_check": (ci, [vp]),
     "fhe_sync": (ci, [vp, vp]),
     "fhe_alloc": (ci, [vp, sz, C.POINTER(vp)]),
     "fhe_free": (ci, [vp, vp]),

@@ -6,7 +6,9 @@
 
 #include <hip/hip_runtime.h>
 
+#include <algorithm>
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <map>
 #include <memory>
@@ -16,6 +18,7 @@
 #include <vector>
 
 #include "host_math.hpp"
+#include "ntt_fused.hpp"
 #include "ntt_launch.hpp"
 
 using namespace fhe;
@@ -90,6 +93,12 @@ struct fhe_ctx {
     int device = 0;
     hipStream_t stream = nullptr;
     std::mutex mu;
+    // fused-NTT control blocks, one per stream the caller launches on (zeroed on that stream per launch)
+    std::map<hipStream_t, std::unique_ptr<DevBuf>> fused_ctl;
+    int mode = 0;          // 0 = two launches per transform (default), 1 = fused launch (experimental)
+    unsigned fused_dist = 4, fused_wgs = 768;
+    unsigned fused_skip_teams = 0;
+    int fused_variant = 7;   // handoff*2 + stream hint (ntt_launch.hpp); 7 = acquire + nt streaming
     // cyclic tables keyed by (log_n, mod, root, convention)
     std::map<std::tuple<int, u64, u64, int>, std::unique_ptr<fhe_ntt_tables>> cyclic;
     std::map<std::vector<u64>, std::unique_ptr<GarnerTables>> garner;
@@ -234,7 +243,25 @@ int ntt_batch(fhe_ctx *ctx, u64 *d, const fhe_ntt_tables *t, size_t n_poly, size
     const size_t N = (size_t)1 << t->log_n;
     return for_each_run(t, limbs, start_idx, [&](size_t off, size_t len, int path) -> int {
         PassArgs a{d + off * N, t->d_lp.as<LimbParams>(), (u32)(start_idx + off), (u32)len, (u32)(n_poly * len), (u32)limbs};
-        hipError_t e = launch_ntt(st, a, t->log_n, inverse, path);
+        hipError_t e;
+        if (ctx->mode == 1 && fused_supported(t->log_n)) {
+            DevBuf *ctl;
+            {
+                std::lock_guard<std::mutex> lock(ctx->mu);
+                auto &slot = ctx->fused_ctl[st];
+                if (!slot) slot.reset(new DevBuf);
+                ctl = slot.get();
+            }
+            const size_t need = fused_ctl_bytes(a.units);
+            if (ctl->bytes < need) {
+                // growing frees the old block: make sure no launch on this stream still uses it
+                HIP_TRY(hipStreamSynchronize(st));
+                HIP_TRY(ctl->alloc(need * 2));
+            }
+            e = launch_ntt_fused(st, a, t->log_n, inverse, path, ctl->as<u32>(), ctx->fused_dist, ctx->fused_wgs, ctx->fused_variant, ctx->fused_skip_teams);
+        } else {
+            e = launch_ntt(st, a, t->log_n, inverse, path);
+        }
         if (e != hipSuccess) return hip_fail(e, "launch_ntt");
         return FHE_OK;
     });
@@ -283,6 +310,10 @@ int fhe_ctx_create(int device, fhe_ctx **out)
     std::unique_ptr<fhe_ctx> c(new fhe_ctx);
     c->device = device;
     HIP_TRY(hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking));
+    // tuning knobs: FHE_NTT_MODE=twopass|fused, FHE_FUSED_DIST, FHE_FUSED_WGS
+    if (const char *m = getenv("FHE_NTT_MODE")) c->mode = std::strcmp(m, "fused") == 0 ? 1 : 0;
+    if (const char *v = getenv("FHE_FUSED_DIST")) c->fused_dist = (unsigned)std::max(1, atoi(v));
+    if (const char *v = getenv("FHE_FUSED_WGS")) c->fused_wgs = (unsigned)std::max(1, atoi(v));
     *out = c.release();
     return FHE_OK;
 }
@@ -294,8 +325,36 @@ int fhe_ctx_destroy(fhe_ctx *ctx)
     (void)hipStreamSynchronize(ctx->stream);
     ctx->cyclic.clear();
     ctx->garner.clear();
+    ctx->fused_ctl.clear();
     (void)hipStreamDestroy(ctx->stream);
     delete ctx;
+    return FHE_OK;
+}
+
+int fhe_ctx_set_option(fhe_ctx *ctx, const char *name, long value)
+{
+    if (!ctx || !name) return fail(FHE_ERR_INVALID, "null argument");
+    if (!std::strcmp(name, "ntt_mode")) ctx->mode = value ? 1 : 0;
+    else if (!std::strcmp(name, "fused_dist")) ctx->fused_dist = (unsigned)std::max(1l, value);
+    else if (!std::strcmp(name, "fused_wgs")) ctx->fused_wgs = (unsigned)std::max(1l, value);
+    else if (!std::strcmp(name, "fused_variant")) ctx->fused_variant = (int)value;
+    else if (!std::strcmp(name, "fused_skip_teams")) ctx->fused_skip_teams = (unsigned)value;   // test hook
+    else return fail(FHE_ERR_INVALID, "unknown option");
+    return FHE_OK;
+}
+
+int fhe_ctx_check(fhe_ctx *ctx)
+{
+    if (!ctx) return fail(FHE_ERR_INVALID, "null ctx");
+    HIP_TRY(hipSetDevice(ctx->device));
+    std::lock_guard<std::mutex> lock(ctx->mu);
+    for (auto &kv : ctx->fused_ctl) {
+        if (!kv.second || !kv.second->p) continue;
+        HIP_TRY(hipStreamSynchronize(kv.first));
+        u32 flag = 0;
+        HIP_TRY(hipMemcpy(&flag, kv.second->as<u32>() + fused_error_word(), sizeof flag, hipMemcpyDeviceToHost));
+        if (flag) return fail(FHE_ERR_HIP, "fused NTT: a bounded wait ran out (results of that launch are invalid)");
+    }
     return FHE_OK;
 }
 

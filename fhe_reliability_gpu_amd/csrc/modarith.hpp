@@ -27,6 +27,19 @@
 #define FHE_HD inline
 #define FHE_D inline
 #endif
+// Twiddle tables are reached through pointers stored in device memory; telling the
+// compiler they are global (address space 1) turns flat_load into global_load /
+// s_load.  Host passes and the CPU emulation see a plain pointer.
+#if defined(__HIP_DEVICE_COMPILE__)
+#define FHE_GLOBAL __attribute__((address_space(1)))
+#else
+#define FHE_GLOBAL
+#endif
+#if defined(__clang__)
+#define FHE_ASSUME(x) __builtin_assume(x)
+#else
+#define FHE_ASSUME(x) ((void)0)
+#endif
 
 namespace fhe {
 
@@ -57,6 +70,40 @@ struct alignas(16) LimbParams {
 
 enum { PATH_F64 = 0, PATH_U64 = 1 };
 
+typedef const Tw FHE_GLOBAL *TwPtr;
+FHE_HD TwPtr as_global(const Tw *p) { return (TwPtr)p; }
+
+// Streaming accesses (touched once per launch): non-temporal hint so they do not displace
+// the fused kernel's hand-off lines and twiddles from the XCD's L2.
+FHE_D u64 load_stream_u64(const u64 *p)
+{
+#if defined(__HIP_DEVICE_COMPILE__)
+    return __builtin_nontemporal_load(p);
+#else
+    return *p;
+#endif
+}
+FHE_D void store_stream_u64(u64 *p, u64 v)
+{
+#if defined(__HIP_DEVICE_COMPILE__)
+    __builtin_nontemporal_store(v, p);
+#else
+    *p = v;
+#endif
+}
+
+// 64-bit load that must observe data another workgroup of the same XCD has stored
+// and drained to L2 (fused NTT hand-off): agent-scope relaxed atomic load =
+// global_load_dwordx2 sc1, served by L2, never by this CU's L1.
+FHE_D u64 load_coherent_u64(const u64 *p)
+{
+#if defined(__HIP_DEVICE_COMPILE__)
+    return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+#else
+    return *p;
+#endif
+}
+
 FHE_HD u64 mulhi64(u64 a, u64 b)
 {
 #if defined(__HIP_DEVICE_COMPILE__)
@@ -71,7 +118,11 @@ FHE_HD u64 double_to_u64_bits(double d) { return __builtin_bit_cast(u64, d); }
 
 // Full reduction of an arbitrary 64-bit word (only reached for out-of-range inputs,
 // e.g. the bit-flipped symbols of reliability_test/ntt_test.cu:104-135).
-FHE_HD u64 reduce_any_u64(u64 x, u64 q) { return x % q; }
+#if defined(__HIPCC__)
+__host__ __device__ __attribute__((noinline)) inline u64 reduce_any_u64(u64 x, u64 q) { return x % q; }
+#else
+inline u64 reduce_any_u64(u64 x, u64 q) { return x % q; }
+#endif
 
 // ---------------------------------------------------------------------------
 // ArithF64

@@ -14,9 +14,11 @@
 // contiguous index, so every global and LDS access is coalesced); the "row pass"
 // performs the PR stages inside contiguous rows of 2^PR points.  Inside a pass a
 // thread keeps 2^K points in registers for K stages (K <= 4), and the points are
-// exchanged through LDS between such steps.
+// exchanged through LDS between such steps.  A register step whose points are
+// adjacent in memory (stride 1) never touches global memory directly: the tile is
+// staged through LDS so that HBM only sees whole-line, lane-contiguous accesses.
 //
-// Everything here is callable per (thread id, step) so that tests/emu can run the
+// Everything here is callable per (thread id, phase) so that tests/emu can run the
 // exact same code on the CPU with a loop standing in for the workgroup.
 #pragma once
 #include "modarith.hpp"
@@ -24,6 +26,7 @@
 namespace fhe {
 
 FHE_HD constexpr int cmax(int a, int b) { return a > b ? a : b; }
+FHE_HD constexpr int cmin(int a, int b) { return a < b ? a : b; }
 
 // Lazy-range schedule for ArithF64: bit u of the mask = "reduce all registers
 // before stage u of this pass".  `stage0` is the number of stages already done
@@ -42,7 +45,7 @@ FHE_HD constexpr u32 reduce_mask(int stage0, int nstages, int first, int next)
 // field (most significant bit = first stage) equals r.  `s` = global index of the
 // first stage, `prefix` = value of the s index bits above the field.
 template <class A, int K, u32 RED, int U0>
-FHE_D void radix_fwd(typename A::elem (&x)[1 << K], const Tw *__restrict__ tw, u32 s, u32 prefix, const typename A::Ctx &c)
+FHE_D void radix_fwd(typename A::elem (&x)[1 << K], TwPtr tw, u32 s, u32 prefix, const typename A::Ctx &c)
 {
     constexpr int R = 1 << K;
 #pragma unroll
@@ -63,7 +66,7 @@ FHE_D void radix_fwd(typename A::elem (&x)[1 << K], const Tw *__restrict__ tw, u
 
 // K inverse stages, undoing radix_fwd: forward stage s+K-1 first.
 template <class A, int K, u32 RED, int U0>
-FHE_D void radix_inv(typename A::elem (&x)[1 << K], const Tw *__restrict__ tw, u32 s, u32 prefix, const typename A::Ctx &c)
+FHE_D void radix_inv(typename A::elem (&x)[1 << K], TwPtr tw, u32 s, u32 prefix, const typename A::Ctx &c)
 {
     constexpr int R = 1 << K;
 #pragma unroll
@@ -94,19 +97,46 @@ struct Steps {
     FHE_HD static constexpr int done(int e) { return e == 0 ? 0 : e == 1 ? K0_ : K0_ + K1_; } // stages before step e
 };
 
-// Row-pass LDS image: 16 bytes of padding after every 16 points keeps the
-// 128-byte-per-lane ds_read_b128 / ds_write_b128 of the contiguous step conflict free.
-FHE_HD constexpr u32 row_pad(u32 g) { return g + ((g >> 4) << 1); }
-
 enum IoMode { IO_CANONICAL = 0, IO_LAZY = 1 };
+
+// raw 64-bit words -> arithmetic elements, with ONE branch for the out-of-range case
+template <class A, int R, int IN_MODE>
+FHE_D void convert_in(typename A::elem (&x)[R], u64 (&raw)[R], const typename A::Ctx &c)
+{
+    if (IN_MODE == IO_LAZY) {
+#pragma unroll
+        for (int r = 0; r < R; r++) x[r] = A::load_lazy(raw[r]);
+    } else {
+        bool bad = false;
+#pragma unroll
+        for (int r = 0; r < R; r++) bad |= !A::in_range(raw[r], c);
+        if (__builtin_expect(bad, 0)) {
+#pragma unroll
+            for (int r = 0; r < R; r++) raw[r] = A::in_range(raw[r], c) ? raw[r] : reduce_any_u64(raw[r], c.q);
+        }
+#pragma unroll
+        for (int r = 0; r < R; r++) x[r] = A::from_canonical(raw[r]);
+    }
+}
+
+template <class A, int OUT_MODE, bool INVERSE>
+FHE_D u64 convert_out(typename A::elem x, const typename A::Ctx &c, const Tw &inv_n)
+{
+    if (OUT_MODE == IO_LAZY) return A::store_lazy(x);
+    if (INVERSE) return A::canonical(A::mulmod(x, inv_n, c), c);
+    return A::canonical(x, c);
+}
 
 // ---------------------------------------------------------------------------
 // Column pass: stages [S0, S0+P) of a transform of 2^LOGN points whose pair
 // distances are multiples of STRIDE = 2^(LOGN-S0-P); the tile is TC adjacent
 // "columns" (consecutive values of the low index bits).  With S0 = 0 this is the
 // first pass of the forward transform / last pass of the inverse.
+// LDS image: [point][column], 8-byte elements; TC extra elements after every 16
+// points keep the stride-1 step's ds_read_b64 conflict free when TC < 32.
 // ---------------------------------------------------------------------------
-template <class A, class ST, int LOGN, int S0, int TC, int NTHREADS, bool INVERSE, int IN_MODE, int OUT_MODE, u32 RED>
+template <class A, class ST, int LOGN, int S0, int TC, int NTHREADS, bool INVERSE, int IN_MODE, int OUT_MODE, u32 RED,
+          int COHERENT_IN = 0, bool STREAM = false>
 struct ColPass {
     typedef A Arith;
     typedef typename A::elem elem;
@@ -114,16 +144,20 @@ struct ColPass {
     static constexpr int NPTS = 1 << P;
     static constexpr int LOGSTRIDE = LOGN - S0 - P;
     static constexpr u32 STRIDE = 1u << LOGSTRIDE;      // distance between consecutive points of a column
-    static constexpr int LDS_ELEMS = NPTS * TC;
+    static constexpr int PADC = (TC < 32 && (NPTS * TC + ((NPTS + 15) / 16) * TC) * 8 <= 65536) ? TC : 0;
+    static constexpr int LDS_ELEMS = NPTS * TC + ((NPTS + 15) / 16) * PADC;
     static constexpr int TCOLS = TC;
     static constexpr int NSTEP = ST::NSTEP;
+    static constexpr int NPHASE = ST::NSTEP;             // barrier-separated phases
     static constexpr int TILES = (1 << (LOGN - P)) / TC; // tiles per limb (per outer block when S0 > 0)
 
+    static FHE_HD u32 lidx(u32 g, u32 col) { return g * TC + col + (g >> 4) * PADC; }
+
     // `base` points at the first element of this tile's column 0, point 0.
-    // step index e counts in execution order (for the inverse the field order is reversed).
+    // Phase index E counts in execution order (for the inverse the field order is reversed).
     template <int E>
-    static FHE_D void step(int tid, u64 *__restrict__ base, elem *__restrict__ lds, const Tw *__restrict__ tw,
-                           u32 hi_prefix, const typename A::Ctx &c, const Tw &inv_n)
+    static FHE_D void phase(int tid, u64 *__restrict__ base, elem *__restrict__ lds, TwPtr tw, u32 hi_prefix,
+                            const typename A::Ctx &c, const Tw &inv_n)
     {
         constexpr int F = INVERSE ? ST::NSTEP - 1 - E : E;   // which field (forward numbering) this step handles
         constexpr int K = ST::k(F);
@@ -134,25 +168,25 @@ struct ColPass {
         constexpr int NSETS = NPTS / R;
         constexpr bool FIRST = E == 0, LAST = E == ST::NSTEP - 1;
         constexpr int U0 = INVERSE ? (P - DONE - K) : DONE;  // stage offset inside the pass, execution order
+        FHE_ASSUME(tid >= 0 && tid < NTHREADS);
 #pragma unroll 1
         for (int u = tid; u < NSETS * TC; u += NTHREADS) {
             const u32 col = (u32)u % TC, su = (u32)u / TC;
-            const u32 a = su >> LOGS, cc = su & (S - 1);
+            // DONE == 0: the field is the top of the index, a is identically 0 (keeps the twiddle index uniform)
+            const u32 a = DONE == 0 ? 0u : su >> LOGS, cc = DONE == 0 ? su : su & (S - 1);
             const u32 g0 = ((a << K) << LOGS) + cc;          // point index of register 0
             elem x[R];
             if (FIRST) {
+                u64 raw[R];
 #pragma unroll
                 for (int r = 0; r < R; r++) {
-                    u64 raw = base[(size_t)(g0 + ((u32)r << LOGS)) * STRIDE + col];
-                    if (IN_MODE == IO_LAZY) x[r] = A::load_lazy(raw);
-                    else {
-                        if (!A::in_range(raw, c)) raw = reduce_any_u64(raw, c.q);
-                        x[r] = A::from_canonical(raw);
-                    }
+                    const u64 *src = base + (size_t)(g0 + ((u32)r << LOGS)) * STRIDE + col;
+                    raw[r] = COHERENT_IN == 1 ? load_coherent_u64(src) : (COHERENT_IN == 2 || (STREAM && IN_MODE == IO_CANONICAL)) ? load_stream_u64(src) : *src;
                 }
+                convert_in<A, R, IN_MODE>(x, raw, c);
             } else {
 #pragma unroll
-                for (int r = 0; r < R; r++) x[r] = lds[(g0 + ((u32)r << LOGS)) * TC + col];
+                for (int r = 0; r < R; r++) x[r] = lds[lidx(g0 + ((u32)r << LOGS), col)];
             }
             const u32 prefix = (hi_prefix << DONE) | a;
             if (INVERSE) radix_inv<A, K, RED, U0>(x, tw, S0 + DONE, prefix, c);
@@ -160,15 +194,14 @@ struct ColPass {
             if (LAST) {
 #pragma unroll
                 for (int r = 0; r < R; r++) {
-                    u64 out;
-                    if (OUT_MODE == IO_LAZY) out = A::store_lazy(x[r]);
-                    else if (INVERSE) out = A::canonical(A::mulmod(x[r], inv_n, c), c);
-                    else out = A::canonical(x[r], c);
-                    base[(size_t)(g0 + ((u32)r << LOGS)) * STRIDE + col] = out;
+                    u64 *dst = base + (size_t)(g0 + ((u32)r << LOGS)) * STRIDE + col;
+                    const u64 out = convert_out<A, OUT_MODE, INVERSE>(x[r], c, inv_n);
+                    if (STREAM && OUT_MODE == IO_CANONICAL) store_stream_u64(dst, out);
+                    else *dst = out;
                 }
             } else {
 #pragma unroll
-                for (int r = 0; r < R; r++) lds[(g0 + ((u32)r << LOGS)) * TC + col] = x[r];
+                for (int r = 0; r < R; r++) lds[lidx(g0 + ((u32)r << LOGS), col)] = x[r];
             }
         }
     }
@@ -177,8 +210,16 @@ struct ColPass {
 // ---------------------------------------------------------------------------
 // Row pass: the last P forward stages (pair distance < 2^P) on a tile of TR
 // contiguous rows of 2^P points.
+// LDS image: [row][point], 16 bytes of padding after every 16 points (row_pad): the
+// stride-1 step moves 128 bytes per lane with ds_read_b128 / ds_write_b128 and stays
+// conflict free.  The stride-1 step is the LAST one of a forward pass and the FIRST
+// one of an inverse pass; on that side the tile goes HBM <-> LDS in a separate,
+// fully coalesced copy phase (16 bytes per lane, lanes contiguous).
 // ---------------------------------------------------------------------------
-template <class A, class ST, int LOGN, int TR, int NTHREADS, bool INVERSE, int IN_MODE, int OUT_MODE, u32 RED>
+FHE_HD constexpr u32 row_pad(u32 g) { return g + ((g >> 4) << 1); }
+
+template <class A, class ST, int LOGN, int TR, int NTHREADS, bool INVERSE, int IN_MODE, int OUT_MODE, u32 RED,
+          int COHERENT_IN = 0, bool STREAM = false>
 struct RowPass {
     typedef A Arith;
     typedef typename A::elem elem;
@@ -189,59 +230,115 @@ struct RowPass {
     static constexpr int LDS_ELEMS = ROW_LDS * TR;
     static constexpr int TROWS = TR;
     static constexpr int NSTEP = ST::NSTEP;
+    static constexpr bool STAGED = NPTS >= 32;                   // copy phase on the stride-1 side
+    static constexpr int NPHASE = ST::NSTEP + (STAGED ? 1 : 0);
     static constexpr int TILES = (1 << S0) / TR;
+
+    // coalesced copy HBM -> LDS (inverse, raw words): 2 points (16 bytes) per lane
+    static FHE_D void copy_in(int tid, const u64 *__restrict__ base, elem *__restrict__ lds)
+    {
+#pragma unroll 2
+        for (int i = tid; i < TR * NPTS / 2; i += NTHREADS) {
+            const u32 row = (u32)i / (NPTS / 2), g = ((u32)i % (NPTS / 2)) * 2;
+            const u64 *src = base + (size_t)row * NPTS + g;
+            u64 v0, v1;
+            if (COHERENT_IN == 1) {
+                v0 = load_coherent_u64(src);
+                v1 = load_coherent_u64(src + 1);
+            } else if (COHERENT_IN == 2 || (STREAM && IN_MODE == IO_CANONICAL)) {
+                v0 = load_stream_u64(src);
+                v1 = load_stream_u64(src + 1);
+            } else {
+                v0 = src[0];
+                v1 = src[1];
+            }
+            elem *dst = lds + row * ROW_LDS + row_pad(g);
+            dst[0] = __builtin_bit_cast(elem, v0);
+            dst[1] = __builtin_bit_cast(elem, v1);
+        }
+    }
+    // coalesced copy LDS -> HBM (forward; the image already holds final 64-bit words)
+    static FHE_D void copy_out(int tid, u64 *__restrict__ base, const elem *__restrict__ lds)
+    {
+#pragma unroll 2
+        for (int i = tid; i < TR * NPTS / 2; i += NTHREADS) {
+            const u32 row = (u32)i / (NPTS / 2), g = ((u32)i % (NPTS / 2)) * 2;
+            const elem *src = lds + row * ROW_LDS + row_pad(g);
+            u64 *dst = base + (size_t)row * NPTS + g;
+            if (STREAM && OUT_MODE == IO_CANONICAL) {
+                store_stream_u64(dst, __builtin_bit_cast(u64, src[0]));
+                store_stream_u64(dst + 1, __builtin_bit_cast(u64, src[1]));
+            } else {
+                dst[0] = __builtin_bit_cast(u64, src[0]);
+                dst[1] = __builtin_bit_cast(u64, src[1]);
+            }
+        }
+    }
 
     // `base` = first element of the tile's first row; `row0` = index of that row in the limb.
     template <int E>
-    static FHE_D void step(int tid, u64 *__restrict__ base, elem *__restrict__ lds, const Tw *__restrict__ tw,
-                           u32 row0, const typename A::Ctx &c, const Tw &inv_n)
+    static FHE_D void phase(int tid, u64 *__restrict__ base, elem *__restrict__ lds, TwPtr tw, u32 row0,
+                            const typename A::Ctx &c, const Tw &inv_n)
     {
-        constexpr int F = INVERSE ? ST::NSTEP - 1 - E : E;
-        constexpr int K = ST::k(F);
-        constexpr int R = 1 << K;
-        constexpr int DONE = ST::done(F);
-        constexpr int LOGS = P - DONE - K;
-        constexpr u32 S = 1u << LOGS;
-        constexpr int NSETS = NPTS / R;
-        constexpr bool FIRST = E == 0, LAST = E == ST::NSTEP - 1;
-        constexpr int U0 = INVERSE ? (P - DONE - K) : DONE;
+        if constexpr (STAGED && INVERSE && E == 0) {
+            copy_in(tid, base, lds);
+        } else if constexpr (STAGED && !INVERSE && E == ST::NSTEP) {
+            copy_out(tid, base, lds);
+        } else {
+            constexpr int SE = (STAGED && INVERSE) ? E - 1 : E;   // register-step index in execution order
+            constexpr int F = INVERSE ? ST::NSTEP - 1 - SE : SE;
+            constexpr int K = ST::k(F);
+            constexpr int R = 1 << K;
+            constexpr int DONE = ST::done(F);
+            constexpr int LOGS = P - DONE - K;
+            constexpr u32 S = 1u << LOGS;
+            constexpr int NSETS = NPTS / R;
+            constexpr bool FIRST = SE == 0, LAST = SE == ST::NSTEP - 1;
+            constexpr bool FROM_GLOBAL = FIRST && !(STAGED && INVERSE);
+            constexpr bool TO_GLOBAL = LAST && !(STAGED && !INVERSE);
+            constexpr int U0 = INVERSE ? (P - DONE - K) : DONE;
+            FHE_ASSUME(tid >= 0 && tid < NTHREADS);
 #pragma unroll 1
-        for (int u = tid; u < NSETS * TR; u += NTHREADS) {
-            const u32 row = (u32)u / NSETS, su = (u32)u % NSETS;
-            const u32 a = su >> LOGS, cc = su & (S - 1);
-            const u32 g0 = ((a << K) << LOGS) + cc;
-            u64 *__restrict__ grow = base + (size_t)row * NPTS;
-            elem *__restrict__ lrow = lds + row * ROW_LDS;
-            elem x[R];
-            if (FIRST) {
+            for (int u = tid; u < NSETS * TR; u += NTHREADS) {
+                const u32 row = (u32)u / NSETS, su = (u32)u % NSETS;
+                const u32 a = su >> LOGS, cc = su & (S - 1);
+                const u32 g0 = ((a << K) << LOGS) + cc;
+                u64 *__restrict__ grow = base + (size_t)row * NPTS;
+                elem *__restrict__ lrow = lds + row * ROW_LDS;
+                elem x[R];
+                if (FIRST) {
+                    u64 raw[R];
 #pragma unroll
-                for (int r = 0; r < R; r++) {
-                    u64 raw = grow[g0 + ((u32)r << LOGS)];
-                    if (IN_MODE == IO_LAZY) x[r] = A::load_lazy(raw);
-                    else {
-                        if (!A::in_range(raw, c)) raw = reduce_any_u64(raw, c.q);
-                        x[r] = A::from_canonical(raw);
+                    for (int r = 0; r < R; r++) {
+                        if (FROM_GLOBAL) {
+                            const u64 *src = grow + g0 + ((u32)r << LOGS);
+                            raw[r] = COHERENT_IN == 1 ? load_coherent_u64(src) : (COHERENT_IN == 2 || (STREAM && IN_MODE == IO_CANONICAL)) ? load_stream_u64(src) : *src;
+                        } else {
+                            raw[r] = __builtin_bit_cast(u64, lrow[row_pad(g0 + ((u32)r << LOGS))]);
+                        }
                     }
+                    convert_in<A, R, IN_MODE>(x, raw, c);
+                } else {
+#pragma unroll
+                    for (int r = 0; r < R; r++) x[r] = lrow[row_pad(g0 + ((u32)r << LOGS))];
                 }
-            } else {
+                const u32 prefix = ((row0 + row) << DONE) | a;
+                if (INVERSE) radix_inv<A, K, RED, U0>(x, tw, S0 + DONE, prefix, c);
+                else radix_fwd<A, K, RED, U0>(x, tw, S0 + DONE, prefix, c);
+                if (LAST) {
 #pragma unroll
-                for (int r = 0; r < R; r++) x[r] = lrow[row_pad(g0 + ((u32)r << LOGS))];
-            }
-            const u32 prefix = ((row0 + row) << DONE) | a;
-            if (INVERSE) radix_inv<A, K, RED, U0>(x, tw, S0 + DONE, prefix, c);
-            else radix_fwd<A, K, RED, U0>(x, tw, S0 + DONE, prefix, c);
-            if (LAST) {
+                    for (int r = 0; r < R; r++) {
+                        const u64 out = convert_out<A, OUT_MODE, INVERSE>(x[r], c, inv_n);
+                        if (TO_GLOBAL) {
+                            if (STREAM && OUT_MODE == IO_CANONICAL) store_stream_u64(grow + g0 + ((u32)r << LOGS), out);
+                            else grow[g0 + ((u32)r << LOGS)] = out;
+                        }
+                        else lrow[row_pad(g0 + ((u32)r << LOGS))] = __builtin_bit_cast(elem, out);
+                    }
+                } else {
 #pragma unroll
-                for (int r = 0; r < R; r++) {
-                    u64 out;
-                    if (OUT_MODE == IO_LAZY) out = A::store_lazy(x[r]);
-                    else if (INVERSE) out = A::canonical(A::mulmod(x[r], inv_n, c), c);
-                    else out = A::canonical(x[r], c);
-                    grow[g0 + ((u32)r << LOGS)] = out;
+                    for (int r = 0; r < R; r++) lrow[row_pad(g0 + ((u32)r << LOGS))] = x[r];
                 }
-            } else {
-#pragma unroll
-                for (int r = 0; r < R; r++) lrow[row_pad(g0 + ((u32)r << LOGS))] = x[r];
             }
         }
     }

@@ -19,17 +19,21 @@ __global__ __launch_bounds__(NTT_THREADS) void k_ntt_pass(PassArgs a)
     else base = row_tile<PASS, LOGN>(blockIdx.x, a, limb, row0);
     const LimbParams &p = a.lp[limb];
     const typename A::Ctx ctx = A::make_ctx(p);
-    const Tw *tw = INV ? p.inv : p.fwd;
+    const TwPtr tw = as_global(INV ? p.inv : p.fwd);
     const Tw inv_n = p.inv_n;
     const int tid = threadIdx.x;
-    PASS::template step<0>(tid, base, lds, tw, row0, ctx, inv_n);
-    if constexpr (PASS::NSTEP > 1) {
+    PASS::template phase<0>(tid, base, lds, tw, row0, ctx, inv_n);
+    if constexpr (PASS::NPHASE > 1) {
         __syncthreads();
-        PASS::template step<1>(tid, base, lds, tw, row0, ctx, inv_n);
+        PASS::template phase<1>(tid, base, lds, tw, row0, ctx, inv_n);
     }
-    if constexpr (PASS::NSTEP > 2) {
+    if constexpr (PASS::NPHASE > 2) {
         __syncthreads();
-        PASS::template step<2>(tid, base, lds, tw, row0, ctx, inv_n);
+        PASS::template phase<2>(tid, base, lds, tw, row0, ctx, inv_n);
+    }
+    if constexpr (PASS::NPHASE > 3) {
+        __syncthreads();
+        PASS::template phase<3>(tid, base, lds, tw, row0, ctx, inv_n);
     }
 }
 

@@ -9,6 +9,13 @@ namespace fhe {
 // Batched in-place transform of a.units limbs of 2^logn points, all on `path`.
 hipError_t launch_ntt(hipStream_t st, const PassArgs &a, int logn, bool inverse, int path);
 
+// ---- ntt_fused.hip: single-launch variant for two-pass sizes --------------------
+bool fused_supported(int logn);
+size_t fused_ctl_bytes(u32 units);
+// variant = handoff * 2 + stream_hint, handoff: 1 sc1 loads, 2 nt loads, 3 acquire + plain loads
+hipError_t launch_ntt_fused(hipStream_t st, const PassArgs &a, int logn, bool inverse, int path, u32 *ctl, u32 dist, u32 wgs,
+                            int variant, u32 skip_teams);
+
 // ---- aux_kernels.hip --------------------------------------------------------
 struct PointwiseArgs {
     u64 *c;

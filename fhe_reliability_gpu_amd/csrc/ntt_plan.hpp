@@ -41,7 +41,6 @@ FHE_PLAN(19, 4, 3, 3, 3, 3, 3)
 FHE_PLAN(20, 4, 3, 3, 4, 3, 3)
 #undef FHE_PLAN
 
-FHE_HD constexpr int cmin(int a, int b) { return a < b ? a : b; }
 
 template <int LOGN> struct PlanGeom {
     typedef Plan<LOGN> PL;
@@ -81,6 +80,21 @@ struct Passes {
 
 // Block -> work mapping.  One block = one tile of one unit (unit = one limb of one
 // polynomial); the tiles of a unit are adjacent block indices.
+template <class CP, int LOGN>
+FHE_D u64 *col_tile_of(u32 unit, u32 tile, const PassArgs &a, u32 &limb)
+{
+    const u32 poly = unit / a.limbs, l = unit % a.limbs;
+    limb = a.limb0 + l;
+    return a.data + (((size_t)poly * a.poly_stride + l) << LOGN) + (size_t)tile * CP::TCOLS;
+}
+template <class RP, int LOGN>
+FHE_D u64 *row_tile_of(u32 unit, u32 tile, const PassArgs &a, u32 &limb, u32 &row0)
+{
+    const u32 poly = unit / a.limbs, l = unit % a.limbs;
+    limb = a.limb0 + l;
+    row0 = tile * RP::TROWS;
+    return a.data + (((size_t)poly * a.poly_stride + l) << LOGN) + (size_t)row0 * RP::NPTS;
+}
 template <class CP, int LOGN>
 FHE_D u64 *col_tile(u32 block, const PassArgs &a, u32 &limb)
 {

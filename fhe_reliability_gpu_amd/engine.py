@@ -38,6 +38,14 @@ class Engine:
         check(lib.fhe_ctx_stream(h, C.byref(s)))
         self.stream = s
 
+    def set_option(self, name: str, value: int):
+        """``ntt_mode`` (0 two launches / 1 fused), ``fused_dist``, ``fused_wgs`` -- tuning only."""
+        check(lib.fhe_ctx_set_option(self._h, name.encode(), int(value)))
+
+    def check(self):
+        """Synchronise and raise if a fused-NTT launch reported a timed-out wait."""
+        check(lib.fhe_ctx_check(self._h))
+
     def close(self):
         if getattr(self, "_h", None):
             lib.fhe_ctx_destroy(self._h)

@@ -51,6 +51,16 @@ const char *fhe_last_error(void);
 int fhe_ctx_create(int device, fhe_ctx **out);
 int fhe_ctx_destroy(fhe_ctx *ctx);
 int fhe_ctx_stream(fhe_ctx *ctx, void **stream_out);
+/* Tuning knobs (no reference counterpart): "ntt_mode" 0 = two launches per transform
+ * (default), 1 = fused launch with the first-pass -> second-pass hand-off inside one XCD
+ * (experimental, sizes 2^13..2^17); "fused_dist" pipeline distance between a limb's first
+ * and second pass; "fused_wgs" persistent workgroups launched; "fused_variant" hand-off
+ * load flavour.  Environment overrides at context creation: FHE_NTT_MODE=twopass|fused,
+ * FHE_FUSED_DIST, FHE_FUSED_WGS.  Results are identical in every setting. */
+int fhe_ctx_set_option(fhe_ctx *ctx, const char *name, long value);
+/* Synchronises the streams used so far and reports whether any fused-NTT launch hit its
+ * bounded-wait limit (never expected; the kernel then stops instead of hanging). */
+int fhe_ctx_check(fhe_ctx *ctx);
 /* cudaStreamSynchronize (ntt_test.cu:102,151) */
 int fhe_sync(fhe_ctx *ctx, void *stream);
 /* make_cuda_auto_ptr<uint64_t>(n, stream) / its destructor (ntt_test.cu:88) */

@@ -7,7 +7,7 @@
 // never links this file.
 //
 //   g++ -O2 -std=c++17 -ffp-contract=off -shared -fPIC -I<csrc> emu_ntt.cpp -o libemu_ntt.so
-#include "ntt_plan.hpp"
+#include "ntt_fused.hpp"
 
 #include <cmath>
 #include <vector>
@@ -32,13 +32,15 @@ void emu_pass(const PassArgs &a)
         else base = row_tile<PASS, LOGN>(b, a, limb, row0);
         const LimbParams &p = a.lp[limb];
         auto ctx = A::make_ctx(p);
-        const Tw *tw = INV ? p.inv : p.fwd;
-        for (int tid = 0; tid < NTT_THREADS; tid++) PASS::template step<0>(tid, base, lds.data(), tw, row0, ctx, p.inv_n);
-        if constexpr (PASS::NSTEP > 1)
-            for (int tid = 0; tid < NTT_THREADS; tid++) PASS::template step<1>(tid, base, lds.data(), tw, row0, ctx, p.inv_n);
-        if constexpr (PASS::NSTEP > 2)
-            for (int tid = 0; tid < NTT_THREADS; tid++) PASS::template step<2>(tid, base, lds.data(), tw, row0, ctx, p.inv_n);
-        if constexpr (A::PATH == PATH_F64) {
+        const TwPtr tw = as_global(INV ? p.inv : p.fwd);
+        for (int tid = 0; tid < NTT_THREADS; tid++) PASS::template phase<0>(tid, base, lds.data(), tw, row0, ctx, p.inv_n);
+        if constexpr (PASS::NPHASE > 1)
+            for (int tid = 0; tid < NTT_THREADS; tid++) PASS::template phase<1>(tid, base, lds.data(), tw, row0, ctx, p.inv_n);
+        if constexpr (PASS::NPHASE > 2)
+            for (int tid = 0; tid < NTT_THREADS; tid++) PASS::template phase<2>(tid, base, lds.data(), tw, row0, ctx, p.inv_n);
+        if constexpr (PASS::NPHASE > 3)
+            for (int tid = 0; tid < NTT_THREADS; tid++) PASS::template phase<3>(tid, base, lds.data(), tw, row0, ctx, p.inv_n);
+        if constexpr (A::PATH == PATH_F64 && false) {
             for (auto v : lds) {
                 double r = std::fabs((double)v) / p.n;
                 if (r > g_max_ratio) g_max_ratio = r;
@@ -81,6 +83,67 @@ int emu_size(const PassArgs &a, int logn, int inverse)
     }
 }
 
+// the fused kernel's ticket schedule, run by ONE sequential "team": every wait is already
+// satisfied when its ticket comes up, which is exactly the progress argument of ntt_fused.hpp
+template <class PASS, int LOGN, bool INV, bool IS_COL>
+void emu_tile(const PassArgs &a, u32 unit, u32 tile, std::vector<typename PASS::elem> &lds)
+{
+    typedef typename PASS::Arith A;
+    u32 limb, row0 = 0;
+    u64 *base;
+    if constexpr (IS_COL) base = col_tile_of<PASS, LOGN>(unit, tile, a, limb);
+    else base = row_tile_of<PASS, LOGN>(unit, tile, a, limb, row0);
+    const LimbParams &p = a.lp[limb];
+    auto ctx = A::make_ctx(p);
+    const TwPtr tw = as_global(INV ? p.inv : p.fwd);
+    for (int tid = 0; tid < NTT_THREADS; tid++) PASS::template phase<0>(tid, base, lds.data(), tw, row0, ctx, p.inv_n);
+    if constexpr (PASS::NPHASE > 1)
+        for (int tid = 0; tid < NTT_THREADS; tid++) PASS::template phase<1>(tid, base, lds.data(), tw, row0, ctx, p.inv_n);
+    if constexpr (PASS::NPHASE > 2)
+        for (int tid = 0; tid < NTT_THREADS; tid++) PASS::template phase<2>(tid, base, lds.data(), tw, row0, ctx, p.inv_n);
+    if constexpr (PASS::NPHASE > 3)
+        for (int tid = 0; tid < NTT_THREADS; tid++) PASS::template phase<3>(tid, base, lds.data(), tw, row0, ctx, p.inv_n);
+}
+
+template <class A, int LOGN, bool INV>
+int emu_fused(const PassArgs &a, u32 dist)
+{
+    typedef FusedPasses<A, LOGN, INV> FP;
+    std::vector<typename A::elem> lds(FP::LDS_ELEMS);
+    // teams run one after the other here; on the GPU they run concurrently and independently
+    for (u32 x = 0; x < FUSED_TEAMS; x++) {
+        const u32 my_limbs = fused_team_limbs(a.units, x), last_group = my_limbs + dist;
+        std::vector<u32> done(my_limbs + 1, 0);
+        for (u32 t = 0;; t++) {
+            const FusedTicket k = fused_decode(t, FP::T1, FP::T2, dist);
+            if (k.group >= last_group) break;
+            if (k.phase == 0 || k.slot >= my_limbs) continue;
+            const u32 unit = x + FUSED_TEAMS * k.slot;
+            if (k.phase == 1) {
+                if constexpr (INV) emu_tile<typename FP::Row, LOGN, INV, false>(a, unit, k.tile, lds);
+                else emu_tile<typename FP::Col, LOGN, INV, true>(a, unit, k.tile, lds);
+                done[k.slot]++;
+            } else {
+                if (done[k.slot] != FP::T1) return -4;   // a wait that would block: schedule bug
+                if constexpr (INV) emu_tile<typename FP::Col, LOGN, INV, true>(a, unit, k.tile, lds);
+                else emu_tile<typename FP::Row, LOGN, INV, false>(a, unit, k.tile, lds);
+            }
+        }
+    }
+    return 0;
+}
+
+template <class A>
+int emu_fused_size(const PassArgs &a, int logn, int inverse, u32 dist)
+{
+    switch (logn) {
+#define CASE(L) case L: return inverse ? emu_fused<A, L, true>(a, dist) : emu_fused<A, L, false>(a, dist);
+        CASE(13) CASE(14) CASE(15) CASE(16) CASE(17)
+#undef CASE
+    default: return -1;
+    }
+}
+
 u64 invmod(u64 a, u64 m)
 {
     __int128 t = 0, nt = 1, r = m, nr = a % m;
@@ -97,7 +160,8 @@ u64 invmod(u64 a, u64 m)
 
 // data: [n_poly][limbs][N] in place.  q: limbs moduli.  rp: limbs x N forward tables
 // (canonical residues, entry k = psi^bitrev(k)).  path: 0 = ArithF64, 1 = ArithU64.
-extern "C" int emu_ntt(u64 *data, int logn, int inverse, int n_poly, int limbs, const u64 *q, const u64 *rp, int path)
+extern "C" int emu_ntt(u64 *data, int logn, int inverse, int n_poly, int limbs, const u64 *q, const u64 *rp, int path,
+                       int fused_dist)
 {
     const size_t N = (size_t)1 << logn;
     std::vector<LimbParams> lp(limbs);
@@ -123,6 +187,9 @@ extern "C" int emu_ntt(u64 *data, int logn, int inverse, int n_poly, int limbs, 
     }
     PassArgs a{data, lp.data(), 0u, (u32)limbs, (u32)(n_poly * limbs), (u32)limbs};
     g_max_ratio = 0.0;
+    if (fused_dist > 0)
+        return path == PATH_F64 ? emu_fused_size<ArithF64>(a, logn, inverse, (u32)fused_dist)
+                                : emu_fused_size<ArithU64>(a, logn, inverse, (u32)fused_dist);
     return path == PATH_F64 ? emu_size<ArithF64>(a, logn, inverse) : emu_size<ArithU64>(a, logn, inverse);
 }
 

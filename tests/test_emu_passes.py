@@ -20,24 +20,24 @@ p64 = C.POINTER(C.c_uint64)
 @pytest.fixture(scope="module")
 def emu():
     so = os.path.join(EMU_DIR, "libemu_ntt.so")
-    srcs = [os.path.join(EMU_DIR, "emu_ntt.cpp")] + [os.path.join(CSRC, f) for f in ("modarith.hpp", "ntt_core.hpp", "ntt_plan.hpp")]
+    srcs = [os.path.join(EMU_DIR, "emu_ntt.cpp")] + [os.path.join(CSRC, f) for f in ("modarith.hpp", "ntt_core.hpp", "ntt_plan.hpp", "ntt_fused.hpp")]
     if not os.path.exists(so) or os.path.getmtime(so) < max(os.path.getmtime(s) for s in srcs):
         subprocess.check_call(["g++", "-O2", "-std=c++17", "-ffp-contract=off", "-shared", "-fPIC", "-I" + CSRC,
                                srcs[0], "-o", so])
     L = C.CDLL(so)
     L.emu_ntt.restype = C.c_int
-    L.emu_ntt.argtypes = [p64, C.c_int, C.c_int, C.c_int, C.c_int, p64, p64, C.c_int]
+    L.emu_ntt.argtypes = [p64, C.c_int, C.c_int, C.c_int, C.c_int, p64, p64, C.c_int, C.c_int]
     L.emu_max_ratio.restype = C.c_double
     return L
 
 
-def _run(emu, data, logn, inverse, qs, rps, path):
+def _run(emu, data, logn, inverse, qs, rps, path, fused_dist=0):
     d = np.ascontiguousarray(data, dtype=np.uint64).copy()
     n_poly, limbs, _ = d.shape
     q = np.asarray(qs, dtype=np.uint64)
     rp = np.ascontiguousarray(rps, dtype=np.uint64)
-    rc = emu.emu_ntt(d.ctypes.data_as(p64), logn, inverse, n_poly, limbs, q.ctypes.data_as(p64), rp.ctypes.data_as(p64), path)
-    assert rc == 0
+    rc = emu.emu_ntt(d.ctypes.data_as(p64), logn, inverse, n_poly, limbs, q.ctypes.data_as(p64), rp.ctypes.data_as(p64), path, fused_dist)
+    assert rc == 0, rc
     return d
 
 
@@ -89,3 +89,22 @@ def test_out_of_range_words_are_reduced_first(emu, path):
     assert (fwd[0, 0] == O.nwt_forward(data[0, 0], qs[0], rps[0])).all()
     inv = _run(emu, data, logn, 1, qs, rps, path)
     assert (inv[0, 0] == O.nwt_inverse(data[0, 0], qs[0], rps[0])).all()
+
+
+@pytest.mark.parametrize("logn", [13, 14, 15, 16, 17])
+@pytest.mark.parametrize("path,bits", [(0, 50), (1, 61)])
+@pytest.mark.parametrize("dist", [1, 3, 9])
+def test_fused_schedule_matches_oracle(emu, logn, path, bits, dist):
+    # the single-launch kernel's ticket schedule and tile geometry, run by one sequential team
+    # (dist = 9 > number of limbs: the team runs out of limbs before its first second pass)
+    N = 1 << logn
+    limbs, n_poly = (2, 3) if logn <= 15 else (2, 2)
+    qs, rps = _tables(logn, bits, limbs)
+    rng = np.random.default_rng(logn + 100 * path + dist)
+    data = np.stack([np.stack([rng.integers(0, q, N, dtype=np.uint64) for q in qs]) for _ in range(n_poly)])
+    fwd = _run(emu, data, logn, 0, qs, rps, path, fused_dist=dist)
+    for p in range(n_poly):
+        for l in range(limbs):
+            assert (fwd[p, l] == O.nwt_forward(data[p, l], qs[l], rps[l])).all()
+    back = _run(emu, fwd, logn, 1, qs, rps, path, fused_dist=dist)
+    assert (back == data).all()

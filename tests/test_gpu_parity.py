@@ -38,11 +38,21 @@ def _rand_limbs(rng, qs, N, n_poly=1):
 
 
 # ------------------------------------------------------------------ a2 / a3
+@pytest.fixture(params=[1, 0], ids=["fused", "twopass"])
+def mode(request, eng):
+    eng.set_option("ntt_mode", request.param)
+    yield request.param
+    eng.check()
+    eng.set_option("ntt_mode", 0)
+
+
 @pytest.mark.parametrize("logn", list(range(1, 19)))
 @pytest.mark.parametrize("bits", [50, 61, 30])
-def test_forward_inverse_match_oracle(F, eng, O, logn, bits):
+def test_forward_inverse_match_oracle(F, eng, O, logn, bits, mode):
     if bits == 30 and logn > 14:
         pytest.skip("small-modulus FP64 case covered at the smaller sizes")
+    if mode == 1 and not 13 <= logn <= 17:
+        pytest.skip("the fused launch only exists for 2^13..2^17")
     N = 1 << logn
     limbs = 3 if logn <= 14 else (2 if logn <= 16 else 1)
     n_poly = 2 if logn <= 13 else 1
@@ -341,3 +351,46 @@ def test_full_size_round_trip_and_linearity(F, eng, bits):
     want = np.roll(a, 1, axis=2)
     want[:, :, 0] = (qcol[:, :, 0] - want[:, :, 0]) % qcol[:, :, 0]
     assert (out.download() == want).all()
+
+
+# ------------------------------------------------------ fused hand-off under load
+@pytest.mark.parametrize("bits,inverse", [(50, False), (61, False), (50, True)])
+def test_fused_equals_twopass_on_large_batches(F, eng, bits, inverse):
+    """The fused kernel hands a limb from its first to its second pass through one XCD's L2.
+    Compare every word with the two-launch path on batches far larger than the number of
+    resident workgroups, for several pipeline distances and grid sizes (uneven load, warm
+    caches: repeated in-place launches)."""
+    logn, N = 16, 1 << 16
+    limbs, polys = 4, 96                     # 384 limb-polynomials, 192 MiB
+    qs = F.create_moduli(N, [bits] * limbs)
+    t = eng.tables(logn, qs)
+    rng = np.random.default_rng(77)
+    data = _rand_limbs(rng, qs, N, polys)
+    run = (lambda d: t.inverse(d, n_poly=polys)) if inverse else (lambda d: t.forward(d, n_poly=polys))
+    eng.set_option("ntt_mode", 0)
+    d = eng.upload(data)
+    run(d)
+    run(d)                                   # two rounds: second launch starts from warm caches
+    ref = d.download()
+    try:
+        for dist, wgs, variant, skip in ((1, 1024, 7, 0), (2, 300, 2, 0), (4, 768, 3, 0), (7, 512, 4, 0), (3, 64, 5, 0),
+                                         (3, 768, 6, 0), (3, 768, 7, 0b00100101), (2, 512, 2, 0b11111110)):
+            # skip != 0: teams that "received no workgroup" -- their limbs must come out of the fix-up launch
+            eng.set_option("ntt_mode", 1)
+            eng.set_option("fused_dist", dist)
+            eng.set_option("fused_wgs", wgs)
+            eng.set_option("fused_variant", variant)
+            eng.set_option("fused_skip_teams", skip)
+            d2 = eng.upload(data)
+            run(d2)
+            run(d2)
+            eng.check()
+            got = d2.download()
+            assert (got == ref).all(), f"fused(dist={dist}, wgs={wgs}, variant={variant}, skip={skip}) differs in {(got != ref).sum()} words"
+            d2.free()
+    finally:
+        eng.set_option("ntt_mode", 0)
+        eng.set_option("fused_dist", 4)
+        eng.set_option("fused_wgs", 768)
+        eng.set_option("fused_variant", 7)
+        eng.set_option("fused_skip_teams", 0)
