@@ -42,6 +42,7 @@ def main():
     ap.add_argument("--no-cpu", action="store_true", help="skip the CPU baseline leg")
     ap.add_argument("--check", action="store_true", help="verify one limb against the oracle before timing")
     ap.add_argument("--mode", choices=["fused", "twopass"], default="twopass")
+    ap.add_argument("--no-extras", action="store_true", help="skip the secondary measurements (other batch shapes)")
     args = ap.parse_args()
 
     import torch
@@ -140,7 +141,8 @@ def main():
         "dtype": "f64" if args.bits <= 50 else "u64",
         "data": "synthetic",
         "config": {
-            "workload": f"N=2^16 forward NTT, {args.limbs} x {args.bits}-bit prime(s), batch of {args.polys} residue polynomials per GPU, in place, HBM resident",
+            "workload": f"N=2^16 forward NTT, {args.limbs} x {args.bits}-bit prime(s), batch of {args.polys} residue polynomials per GPU "
+                        f"({args.polys * args.limbs * N * 8 >> 20} MiB), in place, resident on the device before the timed region",
             "log_n": LOGN, "limbs": args.limbs, "polys_per_gpu": args.polys, "prime_bits": args.bits,
             "parallelism": f"limb-polynomials sharded over {world} GPU(s), no collective",
         },
@@ -152,6 +154,49 @@ def main():
             "ms_per_step_device": step_ms_dev,
         },
     }
+
+    # HBM/fabric bytes per step from the PMC passes committed under profiles/ (same command,
+    # FETCH_SIZE doubled as MI355X_MICROARCH.md prescribes and as calibrated on this access
+    # pattern, plus WRITE_SIZE); only quoted for the configuration it was collected on
+    tpath = os.path.join(ROOT, "profiles", "traffic.json")
+    if os.path.exists(tpath):
+        with open(tpath) as fh:
+            tr = json.load(fh)
+        key = f"{args.mode}:limbs={args.limbs}:polys={args.polys}:bits={args.bits}"
+        if key in tr:
+            result["roofline"]["traffic"] = tr[key]["bytes_per_step"]
+            result["roofline"]["traffic_note"] = tr[key]["note"]
+
+    # secondary measurements on rank 0 (not the headline): same kernels, other batch shapes
+    if rank == 0 and not args.no_extras and world == 1:
+        def rate(limbs, polys, bits, inverse=False, steps=10):
+            q2 = F.create_moduli(N, [bits] * limbs)
+            t2 = eng.tables(LOGN, q2)
+            buf = torch.empty((polys, limbs, N), dtype=torch.int64, device="cuda")
+            for l, q in enumerate(q2):
+                buf[:, l, :] = torch.randint(0, q, (polys, N), generator=g, device="cuda", dtype=torch.int64)
+            torch.cuda.synchronize()
+            fn = lib.fhe_ntt_inverse_batch if inverse else lib.fhe_ntt_forward_batch
+            call = lambda: check(fn(eng._h, C.c_void_p(buf.data_ptr()), t2._h, polys, limbs, 0, sptr))
+            for _ in range(3):
+                call()
+            torch.cuda.synchronize()
+            a0, a1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            a0.record(stream)
+            for _ in range(steps):
+                call()
+            a1.record(stream)
+            torch.cuda.synchronize()
+            ms = a0.elapsed_time(a1) / steps
+            del buf
+            return {"ntt_per_s": limbs * polys / (ms * 1e-3), "ms_per_step_device": ms,
+                    "frac_of_hbm_roofline": 16.0 * N * limbs * polys / (ms * 1e-3) / 1e9 / HBM_PEAK_GBS}
+        result["also"] = {
+            "inverse_same_batch": rate(args.limbs, args.polys, args.bits, inverse=True),
+            "L16_distinct_primes_x16_polys (configs[2] shape)": rate(16, 16, args.bits),
+            "hbm_streaming_1024_polys_512MiB (exceeds the 256 MiB Infinity Cache)": rate(1, 1024, args.bits, steps=5),
+            "61bit_prime_integer_path": rate(1, args.polys, 61),
+        }
 
     if rank == 0 and not args.no_cpu:
         from oracle import cport as O

@@ -98,6 +98,7 @@ struct fhe_ctx {
     int mode = 0;          // 0 = two launches per transform (default), 1 = fused launch (experimental)
     unsigned fused_dist = 4, fused_wgs = 768;
     unsigned fused_skip_teams = 0;
+    int geo = 1;           // column-tile geometry of the two-launch path (ntt_launch.hpp)
     int fused_variant = 7;   // handoff*2 + stream hint (ntt_launch.hpp); 7 = acquire + nt streaming
     // cyclic tables keyed by (log_n, mod, root, convention)
     std::map<std::tuple<int, u64, u64, int>, std::unique_ptr<fhe_ntt_tables>> cyclic;
@@ -260,7 +261,7 @@ int ntt_batch(fhe_ctx *ctx, u64 *d, const fhe_ntt_tables *t, size_t n_poly, size
             }
             e = launch_ntt_fused(st, a, t->log_n, inverse, path, ctl->as<u32>(), ctx->fused_dist, ctx->fused_wgs, ctx->fused_variant, ctx->fused_skip_teams);
         } else {
-            e = launch_ntt(st, a, t->log_n, inverse, path);
+            e = launch_ntt(st, a, t->log_n, inverse, path, ctx->geo);
         }
         if (e != hipSuccess) return hip_fail(e, "launch_ntt");
         return FHE_OK;
@@ -338,6 +339,7 @@ int fhe_ctx_set_option(fhe_ctx *ctx, const char *name, long value)
     else if (!std::strcmp(name, "fused_dist")) ctx->fused_dist = (unsigned)std::max(1l, value);
     else if (!std::strcmp(name, "fused_wgs")) ctx->fused_wgs = (unsigned)std::max(1l, value);
     else if (!std::strcmp(name, "fused_variant")) ctx->fused_variant = (int)value;
+    else if (!std::strcmp(name, "tile_geo")) ctx->geo = value ? 1 : 0;
     else if (!std::strcmp(name, "fused_skip_teams")) ctx->fused_skip_teams = (unsigned)value;   // test hook
     else return fail(FHE_ERR_INVALID, "unknown option");
     return FHE_OK;

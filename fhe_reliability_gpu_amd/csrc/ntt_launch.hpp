@@ -7,7 +7,8 @@
 namespace fhe {
 
 // Batched in-place transform of a.units limbs of 2^logn points, all on `path`.
-hipError_t launch_ntt(hipStream_t st, const PassArgs &a, int logn, bool inverse, int path);
+// geo: 1 = 16-column tiles (default), 0 = widest column tile (kept for 2^16 tuning runs)
+hipError_t launch_ntt(hipStream_t st, const PassArgs &a, int logn, bool inverse, int path, int geo = 1);
 
 // ---- ntt_fused.hip: single-launch variant for two-pass sizes --------------------
 bool fused_supported(int logn);

@@ -42,12 +42,14 @@ FHE_PLAN(20, 4, 3, 3, 4, 3, 3)
 #undef FHE_PLAN
 
 
-template <int LOGN> struct PlanGeom {
+// GEO 0: largest column tile that fits 64 KiB of LDS (256-byte row segments at 2^16);
+// GEO 1: 16-column tiles (128-byte segments, ~35 KiB of LDS, one register set per thread) so
+// that four workgroups share a CU.
+template <int LOGN, int GEO = 0> struct PlanGeom {
     typedef Plan<LOGN> PL;
     static constexpr int PC = PL::Col::P, PR = PL::Row::P;
     static constexpr bool TWO_PASS = PC > 0;
-    // 64 KiB of LDS per workgroup at most
-    static constexpr int TC = TWO_PASS ? cmin(64, 8192 >> PC) : 1;
+    static constexpr int TC = !TWO_PASS ? 1 : GEO == 0 ? cmin(64, 8192 >> PC) : (PC <= 8 ? 16 : 8);
     static constexpr int TR = !TWO_PASS ? 1 : PR <= 8 ? 16 : PR == 9 ? 8 : 4;
 };
 
@@ -61,9 +63,9 @@ struct PassArgs {
     u32 poly_stride;        // distance between polynomials in units of one limb (>= limbs)
 };
 
-template <class A, int LOGN, bool INVERSE>
+template <class A, int LOGN, bool INVERSE, int GEO = 0>
 struct Passes {
-    typedef PlanGeom<LOGN> G;
+    typedef PlanGeom<LOGN, GEO> G;
     typedef typename G::PL PL;
     static constexpr u32 RED_FIRST = INVERSE ? reduce_mask(0, G::PR, A::INV_FIRST, A::INV_NEXT)
                                              : reduce_mask(0, G::TWO_PASS ? G::PC : G::PR, A::FWD_FIRST, A::FWD_NEXT);

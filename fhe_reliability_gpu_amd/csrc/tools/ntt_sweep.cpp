@@ -53,19 +53,20 @@ int main(int argc, char **argv)
     auto run = [&](void) { return inverse ? fhe_ntt_inverse_batch(ctx, (uint64_t *)d, t, polys, limbs, 0, nullptr)
                                           : fhe_ntt_forward_batch(ctx, (uint64_t *)d, t, polys, limbs, 0, nullptr); };
     struct Cfg { int mode, dist, wgs, nt; };
-    std::vector<Cfg> cfgs = {{0, 0, 0, 0}};
+    std::vector<Cfg> cfgs = {{0, 0, 0, 0}, {0, 1, 0, 0}};   // two-launch path: tile_geo 0 and 1 (in the dist column)
     for (int nt : {2, 3, 4, 5, 6, 7})
         for (int dist : {2, 4})
             for (int wgs : {512, 768}) cfgs.push_back({1, dist, wgs, nt});
     if (const char *e = getenv("SWEEP_WGS")) {
-        cfgs.resize(1);
+        cfgs.resize(2);
         for (int nt : {2, 3, 4, 5, 6, 7})
-            for (int dist : {3}) cfgs.push_back({1, dist, atoi(e), nt});
+            for (int dist : {getenv("SWEEP_DIST") ? atoi(getenv("SWEEP_DIST")) : 3}) cfgs.push_back({1, dist, atoi(e), nt});
     }
     const double alg_bytes = 16.0 * N * limbs * polys;
     printf("# log_n=%d limbs=%d polys=%d bits=%d inverse=%d  (%.1f MiB in place)\n", log_n, limbs, polys, bits, inverse, words * 8 / 1048576.0);
     for (const Cfg &c : cfgs) {
         OK(fhe_ctx_set_option(ctx, "ntt_mode", c.mode));
+        if (!c.mode) OK(fhe_ctx_set_option(ctx, "tile_geo", c.dist));
         if (c.mode) {
             OK(fhe_ctx_set_option(ctx, "fused_dist", c.dist));
             OK(fhe_ctx_set_option(ctx, "fused_wgs", c.wgs));
@@ -77,7 +78,7 @@ int main(int argc, char **argv)
         OK(fhe_sync(ctx, nullptr));
         OK(fhe_ctx_check(ctx));
         size_t bad = 0;
-        if (c.mode == 0) ref = got;
+        if (c.mode == 0 && c.dist == 0) ref = got;
         else
             for (size_t i = 0; i < words; i++) bad += got[i] != ref[i];
         for (int w = 0; w < 3; w++) OK(run());

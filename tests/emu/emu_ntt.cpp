@@ -52,7 +52,7 @@ void emu_pass(const PassArgs &a)
 template <class A, int LOGN, bool INV>
 void emu_transform(const PassArgs &a)
 {
-    typedef Passes<A, LOGN, INV> PS;
+    typedef Passes<A, LOGN, INV, (LOGN >= 13 ? 1 : 0)> PS;   // the geometry launch_ntt uses by default
     if constexpr (!PS::G::TWO_PASS) {
         emu_pass<typename PS::Single, LOGN, INV, false>(a);
     } else if constexpr (!INV) {

@@ -394,3 +394,45 @@ def test_fused_equals_twopass_on_large_batches(F, eng, bits, inverse):
         eng.set_option("fused_wgs", 768)
         eng.set_option("fused_variant", 7)
         eng.set_option("fused_skip_teams", 0)
+
+
+# ------------------------------------------------------- CLI text protocol (b1)
+def _run_cli(name, *args):
+    import os
+    import subprocess
+    exe = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "fhe_reliability_gpu_amd", "bin", name)
+    return subprocess.run([exe, *map(str, args)], stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, timeout=120)
+
+
+def test_ntt_test_cli_protocol():
+    import re
+    # 4-argument form driven by test_scripts/gen_errorimpact.py:19-31 (log_dim 12, batch 1)
+    r = _run_cli("ntt_test", 12, 1, 3, 1)
+    assert r.returncode == 0
+    assert "[2D] Flipping 3 bits across 1 symbols...\n" in r.stdout
+    m = re.search(r"\[FAULT DETECTED\] Bit error: (\d+)/(\d+) = ([0-9.]+), Symbol error: (\d+)/(\d+) = ([0-9.]+)", r.stderr)
+    assert m, r.stderr
+    assert int(m.group(2)) == 4096 * 64 and int(m.group(4)) == int(m.group(5)) == 4096     # symbol error rate 1.0
+    assert 0.33 < float(m.group(3)) < 0.45                                                  # ~25/64 (flipimpact_ntt.csv)
+    assert re.search(r"ERROR! Total bitwise Hamming distance = \d+ \(bit error rate = [0-9.e-]+\)\n"
+                     r"       Affected symbols = 4096/4096 \(symbol error rate = 1\)\n", r.stdout)
+    # two flipped symbols at batch 32: at most two limbs change (exp_log.txt:3 shows 8192/131072)
+    r = _run_cli("ntt_test", 12, 32, 1, 2)
+    m = re.search(r"Symbol error: (\d+)/(\d+)", r.stderr)
+    assert m and int(m.group(2)) == 131072 and int(m.group(1)) in (4096, 8192)
+    # legacy 3-argument form of run_bench_test.sh:9
+    r = _run_cli("ntt_test", 12, 32, 2)
+    assert r.returncode == 0 and "[2D] Flipping 2 unique random bits in the data buffer...\n" in r.stdout
+    assert "[FAULT DETECTED]" in r.stderr
+    # usage / argument errors exit with 1 (ntt_test.cu:203-216)
+    assert _run_cli("ntt_test", 12, 1).returncode == 1
+    assert _run_cli("ntt_test", 12, 1, 0, 1).returncode == 1
+    assert _run_cli("ntt_test", 12, 1, 65, 1).returncode == 1
+
+
+def test_ntt_real_test_cli_all_correct():
+    # run_real_test.sh:24 runs "./ntt_test 17 1 1" on the no-flip build and expects ALL CORRECT
+    r = _run_cli("ntt_real_test", 17, 1, 1)
+    assert r.returncode == 0 and r.stdout == "ALL CORRECT\n" and r.stderr == ""
+    r = _run_cli("ntt_real_test", 16, 4, 1)
+    assert r.stdout == "ALL CORRECT\n"
