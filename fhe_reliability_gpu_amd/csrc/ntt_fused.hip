@@ -56,10 +56,10 @@ __device__ __forceinline__ void second_pass_tile(const PassArgs &a, u32 unit, u3
     else run_tile<typename FP::Row, LOGN, INV, false>(a, unit, tile, lds);
 }
 
-template <class A, int LOGN, bool INV, int HANDOFF, bool STREAM>
-__global__ __launch_bounds__(NTT_THREADS, FUSED_WAVES_PER_SIMD) void k_ntt_fused(FusedArgs f)
+template <class A, int LOGN, bool INV, int HANDOFF, bool STREAM, bool FAT>
+__global__ __launch_bounds__((FusedPasses<A, LOGN, INV, HANDOFF, STREAM, FAT>::NT), (FAT ? 4 : FUSED_WAVES_PER_SIMD)) void k_ntt_fused(FusedArgs f)
 {
-    typedef FusedPasses<A, LOGN, INV, HANDOFF, STREAM> FP;
+    typedef FusedPasses<A, LOGN, INV, HANDOFF, STREAM, FAT> FP;
     __shared__ __attribute__((aligned(16))) typename A::elem lds[FP::LDS_ELEMS];
     __shared__ u32 sh[8];
 
@@ -89,7 +89,6 @@ __global__ __launch_bounds__(NTT_THREADS, FUSED_WAVES_PER_SIMD) void k_ntt_fused
             if (k.group >= last_group) {
                 stop = 1;
             } else {
-                t_next = add_ctl(ticket, 1u);
                 if (k.phase != 0 && k.slot < my_limbs) {
                     unit = xcc + FUSED_TEAMS * k.slot;
                     if (k.phase == 2) {
@@ -105,6 +104,9 @@ __global__ __launch_bounds__(NTT_THREADS, FUSED_WAVES_PER_SIMD) void k_ntt_fused
                         }
                     }
                 }
+                // draw the next ticket now: its round trip overlaps this tile (issued after the poll,
+                // because memory operations of a wave return in order)
+                t_next = add_ctl(ticket, 1u);
             }
             sh[0] = (u32)k.phase;
             sh[1] = unit;
@@ -173,13 +175,13 @@ __global__ __launch_bounds__(NTT_THREADS, FUSED_WAVES_PER_SIMD) void k_ntt_fixup
     }
 }
 
-template <class A, int LOGN, bool INV, int HANDOFF, bool STREAM>
+template <class A, int LOGN, bool INV, int HANDOFF, bool STREAM, bool FAT = false>
 static hipError_t launch_variant(hipStream_t st, const FusedArgs &f, u32 wgs)
 {
-    typedef FusedPasses<A, LOGN, INV, HANDOFF, STREAM> FP;
+    typedef FusedPasses<A, LOGN, INV, HANDOFF, STREAM, FAT> FP;
     const u64 tickets = ((u64)f.pa.units + (u64)FUSED_TEAMS * f.dist) * (FP::T1 + FP::T2);
     const u32 grid = (u32)(tickets < wgs ? tickets : wgs);
-    hipLaunchKernelGGL((k_ntt_fused<A, LOGN, INV, HANDOFF, STREAM>), dim3(grid), dim3(NTT_THREADS), 0, st, f);
+    hipLaunchKernelGGL((k_ntt_fused<A, LOGN, INV, HANDOFF, STREAM, FAT>), dim3(grid), dim3(FP::NT), 0, st, f);
     hipError_t e = hipGetLastError();
     if (e != hipSuccess) return e;
     const u32 fix = f.pa.units < 64 ? f.pa.units : 64;
@@ -198,6 +200,9 @@ static hipError_t launch_fused_t(hipStream_t st, const FusedArgs &f, u32 wgs, in
         case HANDOFF_NT * 2: return launch_variant<A, LOGN, INV, HANDOFF_NT, false>(st, f, wgs);
         case HANDOFF_NT * 2 + 1: return launch_variant<A, LOGN, INV, HANDOFF_NT, true>(st, f, wgs);
         case HANDOFF_ACQUIRE * 2: return launch_variant<A, LOGN, INV, HANDOFF_ACQUIRE, false>(st, f, wgs);
+        case 8 + HANDOFF_SC1 * 2: return launch_variant<A, LOGN, INV, HANDOFF_SC1, false, true>(st, f, wgs);       // fat tiles
+        case 8 + HANDOFF_NT * 2: return launch_variant<A, LOGN, INV, HANDOFF_NT, false, true>(st, f, wgs);
+        case 8 + HANDOFF_ACQUIRE * 2: return launch_variant<A, LOGN, INV, HANDOFF_ACQUIRE, false, true>(st, f, wgs);
         default: return launch_variant<A, LOGN, INV, HANDOFF_ACQUIRE, true>(st, f, wgs);
         }
     } else {

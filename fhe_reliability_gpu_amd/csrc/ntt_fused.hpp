@@ -99,18 +99,35 @@ template <int LOGN> struct FusedGeom {
     static constexpr int TR = PR <= 8 ? 16 : PR == 9 ? 8 : 4;
 };
 
-template <class A, int LOGN, bool INVERSE, int HANDOFF = HANDOFF_SC1, bool STREAM = false>
+// FAT: 512 threads per tile and radix-8 register steps (8 points per thread) at 2^16 -- twice the
+// waves per byte of in-flight tile, i.e. half the L2 footprint for the same number of resident waves.
+template <int LOGN, bool FAT> struct FusedSteps {
+    typedef typename Plan<LOGN>::Col Col;
+    typedef typename Plan<LOGN>::Row Row;
+    static constexpr int NT = NTT_THREADS;
+};
+template <> struct FusedSteps<16, true> {
+    typedef Steps<3, 3, 2> Col;
+    typedef Steps<3, 3, 2> Row;
+    static constexpr int NT = 512;
+};
+
+template <class A, int LOGN, bool INVERSE, int HANDOFF = HANDOFF_SC1, bool STREAM = false, bool FAT = false>
 struct FusedPasses {
     typedef FusedGeom<LOGN> G;
-    typedef typename G::PL PL;
+    struct PL {
+        typedef typename FusedSteps<LOGN, FAT>::Col Col;
+        typedef typename FusedSteps<LOGN, FAT>::Row Row;
+    };
+    static constexpr int NT = FusedSteps<LOGN, FAT>::NT;
     static constexpr u32 RED_FIRST = INVERSE ? reduce_mask(0, G::PR, A::INV_FIRST, A::INV_NEXT)
                                              : reduce_mask(0, G::PC, A::FWD_FIRST, A::FWD_NEXT);
     static constexpr u32 RED_SECOND = INVERSE ? reduce_mask(G::PR, G::PC, A::INV_FIRST, A::INV_NEXT)
                                               : reduce_mask(G::PC, G::PR, A::FWD_FIRST, A::FWD_NEXT);
     static constexpr int LOADS = HANDOFF == HANDOFF_ACQUIRE ? 0 : HANDOFF;   // how the second pass reads the hand-off
-    typedef ColPass<A, typename PL::Col, LOGN, 0, G::TC, NTT_THREADS, INVERSE, INVERSE ? IO_LAZY : IO_CANONICAL,
+    typedef ColPass<A, typename PL::Col, LOGN, 0, G::TC, NT, INVERSE, INVERSE ? IO_LAZY : IO_CANONICAL,
                     INVERSE ? IO_CANONICAL : IO_LAZY, INVERSE ? RED_SECOND : RED_FIRST, INVERSE ? LOADS : 0, STREAM> Col;
-    typedef RowPass<A, typename PL::Row, LOGN, G::TR, NTT_THREADS, INVERSE, INVERSE ? IO_CANONICAL : IO_LAZY,
+    typedef RowPass<A, typename PL::Row, LOGN, G::TR, NT, INVERSE, INVERSE ? IO_CANONICAL : IO_LAZY,
                     INVERSE ? IO_LAZY : IO_CANONICAL, INVERSE ? RED_FIRST : RED_SECOND, INVERSE ? 0 : LOADS, STREAM> Row;
     static constexpr u32 T1 = INVERSE ? Row::TILES : Col::TILES;   // tiles of the pass that runs first
     static constexpr u32 T2 = INVERSE ? Col::TILES : Row::TILES;

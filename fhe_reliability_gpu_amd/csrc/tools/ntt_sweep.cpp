@@ -54,9 +54,9 @@ int main(int argc, char **argv)
                                           : fhe_ntt_forward_batch(ctx, (uint64_t *)d, t, polys, limbs, 0, nullptr); };
     struct Cfg { int mode, dist, wgs, nt; };
     std::vector<Cfg> cfgs = {{0, 0, 0, 0}, {0, 1, 0, 0}};   // two-launch path: tile_geo 0 and 1 (in the dist column)
-    for (int nt : {2, 3, 4, 5, 6, 7})
-        for (int dist : {2, 4})
-            for (int wgs : {512, 768}) cfgs.push_back({1, dist, wgs, nt});
+    for (int nt : {2, 10, 12, 14})
+        for (int dist : {2, 3, 4})
+            for (int wgs : {256, 384, 512, 768}) cfgs.push_back({1, dist, wgs, nt});
     if (const char *e = getenv("SWEEP_WGS")) {
         cfgs.resize(2);
         for (int nt : {2, 3, 4, 5, 6, 7})

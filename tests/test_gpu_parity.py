@@ -374,7 +374,8 @@ def test_fused_equals_twopass_on_large_batches(F, eng, bits, inverse):
     ref = d.download()
     try:
         for dist, wgs, variant, skip in ((1, 1024, 7, 0), (2, 300, 2, 0), (4, 768, 3, 0), (7, 512, 4, 0), (3, 64, 5, 0),
-                                         (3, 768, 6, 0), (3, 768, 7, 0b00100101), (2, 512, 2, 0b11111110)):
+                                         (3, 768, 6, 0), (3, 768, 7, 0b00100101), (2, 512, 2, 0b11111110),
+                                         (2, 384, 10, 0), (3, 512, 12, 0), (4, 256, 14, 0b00010000)):   # 10/12/14: fat tiles
             # skip != 0: teams that "received no workgroup" -- their limbs must come out of the fix-up launch
             eng.set_option("ntt_mode", 1)
             eng.set_option("fused_dist", dist)
