@@ -175,12 +175,12 @@ int build_tables(fhe_ctx *ctx, int log_n, const u64 *q, int count, const u64 *fw
         t->path[l] = path;
         const u64 *row = fwd_rows + (size_t)l * N;
         Tw *f = tw.data() + (size_t)l * 2 * N, *b = f + N;
-        for (size_t k = 0; k < N; k++) f[k] = encode(path, row[k] % q[l], q[l]);
+        for (size_t k = 0; k < N; k++) f[tw_stored_index(log_n, (u32)k)] = encode(path, row[k] % q[l], q[l]);
         bool inv_ok = false;
         if (want_inverse) inv_ok = batch_inverse(row, N, q[l], inv);
         if (inv_ok) {
             inv[0] = 1 % q[l];
-            for (size_t k = 0; k < N; k++) b[k] = encode(path, inv[k], q[l]);
+            for (size_t k = 0; k < N; k++) b[tw_stored_index(log_n, (u32)k)] = encode(path, inv[k], q[l]);
         } else {
             for (size_t k = 0; k < N; k++) b[k] = f[k];
             t->has_inverse = false;

@@ -126,9 +126,9 @@ struct FusedPasses {
                                               : reduce_mask(G::PC, G::PR, A::FWD_FIRST, A::FWD_NEXT);
     static constexpr int LOADS = HANDOFF == HANDOFF_ACQUIRE ? 0 : HANDOFF;   // how the second pass reads the hand-off
     typedef ColPass<A, typename PL::Col, LOGN, 0, G::TC, NT, INVERSE, INVERSE ? IO_LAZY : IO_CANONICAL,
-                    INVERSE ? IO_CANONICAL : IO_LAZY, INVERSE ? RED_SECOND : RED_FIRST, INVERSE ? LOADS : 0, STREAM> Col;
+                    INVERSE ? IO_CANONICAL : IO_LAZY, INVERSE ? RED_SECOND : RED_FIRST, BlkStage<LOGN>::value, INVERSE ? LOADS : 0, STREAM> Col;
     typedef RowPass<A, typename PL::Row, LOGN, G::TR, NT, INVERSE, INVERSE ? IO_CANONICAL : IO_LAZY,
-                    INVERSE ? IO_LAZY : IO_CANONICAL, INVERSE ? RED_FIRST : RED_SECOND, INVERSE ? 0 : LOADS, STREAM> Row;
+                    INVERSE ? IO_LAZY : IO_CANONICAL, INVERSE ? RED_FIRST : RED_SECOND, BlkStage<LOGN>::value, INVERSE ? 0 : LOADS, STREAM> Row;
     static constexpr u32 T1 = INVERSE ? Row::TILES : Col::TILES;   // tiles of the pass that runs first
     static constexpr u32 T2 = INVERSE ? Col::TILES : Row::TILES;
     static constexpr int LDS_ELEMS = cmax(Col::LDS_ELEMS, Row::LDS_ELEMS);

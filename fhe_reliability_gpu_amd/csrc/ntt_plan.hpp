@@ -42,6 +42,31 @@ FHE_PLAN(20, 4, 3, 3, 4, 3, 3)
 #undef FHE_PLAN
 
 
+// First stage whose table entries are stored blocked (ntt_core.hpp tw_index): the stages of the
+// row plan's last register step.  One value per size, used by every kernel variant and by the host
+// code that lays the tables out.
+template <int LOGN> struct BlkStage {
+    typedef typename Plan<LOGN>::Row R;
+    static constexpr int value = LOGN - R::k(R::NSTEP - 1);
+};
+inline int blk_stage_rt(int logn)
+{
+    switch (logn) {
+#define FHE_B(L) case L: return BlkStage<L>::value;
+        FHE_B(1) FHE_B(2) FHE_B(3) FHE_B(4) FHE_B(5) FHE_B(6) FHE_B(7) FHE_B(8) FHE_B(9) FHE_B(10)
+        FHE_B(11) FHE_B(12) FHE_B(13) FHE_B(14) FHE_B(15) FHE_B(16) FHE_B(17) FHE_B(18) FHE_B(19) FHE_B(20)
+#undef FHE_B
+    default: return logn;
+    }
+}
+// natural table position k (= 2^sigma + i) -> position in the stored layout
+inline u32 tw_stored_index(int logn, u32 k)
+{
+    if (k == 0) return 0;
+    const int sigma = 31 - __builtin_clz(k);
+    return tw_index(blk_stage_rt(logn), sigma, k - (1u << sigma));
+}
+
 // GEO 0: largest column tile that fits 64 KiB of LDS (256-byte row segments at 2^16);
 // GEO 1: 16-column tiles (128-byte segments, ~35 KiB of LDS, one register set per thread) so
 // that four workgroups share a CU.
@@ -72,12 +97,13 @@ struct Passes {
     static constexpr u32 RED_SECOND = INVERSE ? reduce_mask(G::PR, G::PC, A::INV_FIRST, A::INV_NEXT)
                                               : reduce_mask(G::PC, G::PR, A::FWD_FIRST, A::FWD_NEXT);
     // single pass
-    typedef RowPass<A, typename PL::Row, LOGN, 1, NTT_THREADS, INVERSE, IO_CANONICAL, IO_CANONICAL, RED_FIRST> Single;
+    static constexpr int SB = BlkStage<LOGN>::value;
+    typedef RowPass<A, typename PL::Row, LOGN, 1, NTT_THREADS, INVERSE, IO_CANONICAL, IO_CANONICAL, RED_FIRST, SB> Single;
     // forward: column pass then row pass; inverse: row pass then column pass
     typedef ColPass<A, typename PL::Col, LOGN, 0, G::TC, NTT_THREADS, INVERSE, INVERSE ? IO_LAZY : IO_CANONICAL,
-                    INVERSE ? IO_CANONICAL : IO_LAZY, INVERSE ? RED_SECOND : RED_FIRST> Col;
+                    INVERSE ? IO_CANONICAL : IO_LAZY, INVERSE ? RED_SECOND : RED_FIRST, SB> Col;
     typedef RowPass<A, typename PL::Row, LOGN, G::TR, NTT_THREADS, INVERSE, INVERSE ? IO_CANONICAL : IO_LAZY,
-                    INVERSE ? IO_LAZY : IO_CANONICAL, INVERSE ? RED_FIRST : RED_SECOND> Row;
+                    INVERSE ? IO_LAZY : IO_CANONICAL, INVERSE ? RED_FIRST : RED_SECOND, SB> Row;
 };
 
 // Block -> work mapping.  One block = one tile of one unit (unit = one limb of one

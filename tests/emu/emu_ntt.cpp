@@ -171,8 +171,9 @@ extern "C" int emu_ntt(u64 *data, int logn, int inverse, int n_poly, int limbs, 
         inv[l].resize(N);
         for (size_t k = 0; k < N; k++) {
             u64 w = rp[(size_t)l * N + k], wi = invmod(w, q[l]);
-            fwd[l][k] = path == PATH_F64 ? ArithF64::encode(w, q[l]) : ArithU64::encode(w, q[l]);
-            inv[l][k] = path == PATH_F64 ? ArithF64::encode(wi, q[l]) : ArithU64::encode(wi, q[l]);
+            const u32 at = tw_stored_index(logn, (u32)k);   // same layout the library uploads
+            fwd[l][at] = path == PATH_F64 ? ArithF64::encode(w, q[l]) : ArithU64::encode(w, q[l]);
+            inv[l][at] = path == PATH_F64 ? ArithF64::encode(wi, q[l]) : ArithU64::encode(wi, q[l]);
         }
         LimbParams &p = lp[l];
         p.q = q[l];
