@@ -10,6 +10,8 @@ from . import _lib  # noqa: F401  (fails loudly when the HIP extension is missin
 from ._lib import FheError  # noqa: F401
 from .engine import (  # noqa: F401
     BaseConv,
+    KeySwitch,
+    automorphism,
     DeviceArray,
     Engine,
     NttTables,

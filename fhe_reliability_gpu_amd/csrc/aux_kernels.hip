@@ -287,6 +287,87 @@ hipError_t launch_crt_garner(hipStream_t st, u64 *x_lo, u64 *x_hi, const u64 *re
     return hipGetLastError();
 }
 
+// ---------------------------------------------------------------------------
+// Key-switch helpers (shape of profile_framewk/build/data/ckks/16384_4:466-539)
+// ---------------------------------------------------------------------------
+// out = (a - b) * s_l mod q_l per limb: the mod-down tail (subtract the converted special-prime part,
+// multiply by P^-1)
+__global__ __launch_bounds__(256) void k_sub_scale(u64 *out, const u64 *a, const u64 *b, const u64 *scal, const LimbParams *lp,
+                                                   u32 limb0, u32 limbs, int logn)
+{
+    const u64 total = (u64)limbs << logn;
+    for (u64 i = blockIdx.x * (u64)blockDim.x + threadIdx.x; i < total; i += (u64)gridDim.x * blockDim.x) {
+        const u32 l = (u32)(i >> logn);
+        const LimbParams &p = lp[limb0 + l];
+        const u64 q = p.q, r0 = p.barrett_lo, r1 = p.barrett_hi;
+        const u64 x = barrett128(a[i], 0, q, r0, r1), y = barrett128(b[i], 0, q, r0, r1);
+        const u64 d = x >= y ? x - y : x + q - y;
+        out[i] = mulmod_b(d, scal[l], q, r0, r1);
+    }
+}
+
+hipError_t launch_sub_scale(hipStream_t st, u64 *out, const u64 *a, const u64 *b, const u64 *scal, const LimbParams *lp, u32 limb0,
+                            u32 limbs, int logn)
+{
+    const u64 total = (u64)limbs << logn;
+    if (!total) return hipSuccess;
+    u64 want = (total + 255) / 256;
+    hipLaunchKernelGGL(k_sub_scale, dim3((u32)(want > 8192 ? 8192 : want)), dim3(256), 0, st, out, a, b, scal, lp, limb0, limbs, logn);
+    return hipGetLastError();
+}
+
+// Galois automorphism x -> x^k (k odd) on coefficient-domain limbs: dst[(i k) mod N] = +-src[i]
+// (the index map behind phantom::rotate_inplace, reliability_test/dotprod_test.cu:146)
+__global__ __launch_bounds__(256) void k_automorphism(u64 *dst, const u64 *src, const LimbParams *lp, u32 limb0, u32 limbs,
+                                                      u32 units, int logn, u32 k)
+{
+    const u64 total = (u64)units << logn;
+    const u32 n = 1u << logn, mask2 = 2 * n - 1;
+    for (u64 g = blockIdx.x * (u64)blockDim.x + threadIdx.x; g < total; g += (u64)gridDim.x * blockDim.x) {
+        const u32 unit = (u32)(g >> logn), i = (u32)g & (n - 1);
+        const u64 q = lp[limb0 + unit % limbs].q;
+        const u32 j = (u32)(((u64)i * k) & mask2);
+        u64 v = src[g] % q;
+        if (j >= n) v = v ? q - v : 0;
+        dst[((u64)unit << logn) + (j & (n - 1))] = v;
+    }
+}
+
+hipError_t launch_automorphism(hipStream_t st, u64 *dst, const u64 *src, const LimbParams *lp, u32 limb0, u32 limbs, u32 units,
+                               int logn, u32 k)
+{
+    const u64 total = (u64)units << logn;
+    if (!total) return hipSuccess;
+    u64 want = (total + 255) / 256;
+    hipLaunchKernelGGL(k_automorphism, dim3((u32)(want > 8192 ? 8192 : want)), dim3(256), 0, st, dst, src, lp, limb0, limbs, units,
+                       logn, k);
+    return hipGetLastError();
+}
+
+// The same map on NTT-domain limbs (bit-reversed order): slot j evaluates at psi^(2 bitrev(j) + 1), and
+// (sigma_k f)(x) = f(x^k), so dst[j] = src[j'] with 2 bitrev(j') + 1 = (2 bitrev(j) + 1) k mod 2N.
+__global__ __launch_bounds__(256) void k_automorphism_ntt(u64 *dst, const u64 *src, u32 units, int logn, u32 k)
+{
+    const u64 total = (u64)units << logn;
+    const u32 n = 1u << logn, mask2 = 2 * n - 1;
+    for (u64 g = blockIdx.x * (u64)blockDim.x + threadIdx.x; g < total; g += (u64)gridDim.x * blockDim.x) {
+        const u32 j = (u32)g & (n - 1);
+        const u32 e = 2 * (__brev(j) >> (32 - logn)) + 1;
+        const u32 e2 = (u32)(((u64)e * k) & mask2);
+        const u32 j2 = __brev((e2 - 1) >> 1) >> (32 - logn);
+        dst[g] = src[(g & ~(u64)(n - 1)) | j2];
+    }
+}
+
+hipError_t launch_automorphism_ntt(hipStream_t st, u64 *dst, const u64 *src, u32 units, int logn, u32 k)
+{
+    const u64 total = (u64)units << logn;
+    if (!total) return hipSuccess;
+    u64 want = (total + 255) / 256;
+    hipLaunchKernelGGL(k_automorphism_ntt, dim3((u32)(want > 8192 ? 8192 : want)), dim3(256), 0, st, dst, src, units, logn, k);
+    return hipGetLastError();
+}
+
 // motivation/bsgs.py:39-52: y_i = sum_j M[(j - i) mod k] (.) v_j.  lp == nullptr keeps
 // the reference's int64 wrap-around (NumPy, no reduction); otherwise mod q.
 __global__ __launch_bounds__(256) void k_bsgs_hadamard(u64 *y, const u64 *M, const u64 *v, int k, int bs, ModConst mc, bool lp)

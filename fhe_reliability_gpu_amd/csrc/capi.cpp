@@ -105,6 +105,21 @@ struct fhe_ctx {
     std::map<std::vector<u64>, std::unique_ptr<GarnerTables>> garner;
 };
 
+struct fhe_keyswitch {
+    fhe_ctx *ctx = nullptr;
+    const fhe_ntt_tables *t = nullptr;
+    int L = 0, K = 0, dnum = 0, alpha = 0, log_n = 0;
+    std::vector<fhe_baseconv *> up;     // per digit: digit primes -> every other prime (ascending index)
+    fhe_baseconv *down = nullptr;       // P -> Q
+    DevBuf pinv;                        // P^-1 mod q_j, j < L
+    DevBuf coef, ext, tmp, acc0, acc1, tP, conv;
+    ~fhe_keyswitch()
+    {
+        for (auto *b : up) fhe_baseconv_destroy(b);
+        fhe_baseconv_destroy(down);
+    }
+};
+
 struct fhe_fourstep {
     fhe_ctx *ctx = nullptr;
     u64 n1 = 0, n2 = 0, mod = 0;
@@ -682,6 +697,135 @@ int fhe_polymul(fhe_ctx *ctx, uint64_t *c, uint64_t *a, uint64_t *b, const fhe_n
     if (b != a && (rc = ntt_batch(ctx, b, t, n_poly, limbs, start_idx, stream, false))) return rc;
     if ((rc = pointwise(ctx, c, a, b, t, n_poly, limbs, start_idx, stream, false))) return rc;
     return ntt_batch(ctx, c, t, n_poly, limbs, start_idx, stream, true);
+}
+
+// ---------------------------------------------------------------- rotation / key switching
+int fhe_automorphism(fhe_ctx *ctx, uint64_t *d_dst, const uint64_t *d_src, const fhe_ntt_tables *t, uint32_t galois_elt,
+                     size_t n_poly, size_t limbs, size_t start_idx, void *stream)
+{
+    if (!ctx || !d_dst || !d_src || d_dst == d_src || !(galois_elt & 1)) return fail(FHE_ERR_INVALID, "bad automorphism arguments");
+    int rc = check_range(t, n_poly, limbs, start_idx);
+    if (rc) return rc;
+    HIP_TRY(hipSetDevice(ctx->device));
+    hipError_t e = launch_automorphism(pick(ctx, stream), d_dst, d_src, t->d_lp.as<LimbParams>(), (u32)start_idx, (u32)limbs,
+                                       (u32)(n_poly * limbs), t->log_n, galois_elt);
+    if (e != hipSuccess) return hip_fail(e, "launch_automorphism");
+    return FHE_OK;
+}
+
+int fhe_automorphism_ntt(fhe_ctx *ctx, uint64_t *d_dst, const uint64_t *d_src, int log_n, uint32_t galois_elt, size_t n_units,
+                         void *stream)
+{
+    if (!ctx || !d_dst || !d_src || d_dst == d_src || !(galois_elt & 1) || log_n < 1 || log_n > 30)
+        return fail(FHE_ERR_INVALID, "bad automorphism arguments");
+    HIP_TRY(hipSetDevice(ctx->device));
+    hipError_t e = launch_automorphism_ntt(pick(ctx, stream), d_dst, d_src, (u32)n_units, log_n, galois_elt);
+    if (e != hipSuccess) return hip_fail(e, "launch_automorphism_ntt");
+    return FHE_OK;
+}
+
+int fhe_keyswitch_create(fhe_ctx *ctx, const fhe_ntt_tables *t, int L, int K, int dnum, fhe_keyswitch **out)
+{
+    if (!ctx || !t || !out || L < 1 || K < 1 || dnum < 1 || dnum > L || L + K > t->count)
+        return fail(FHE_ERR_INVALID, "bad key-switch shape");
+    std::unique_ptr<fhe_keyswitch> p(new fhe_keyswitch);
+    p->ctx = ctx;
+    p->t = t;
+    p->L = L;
+    p->K = K;
+    p->dnum = dnum;
+    p->alpha = (L + dnum - 1) / dnum;
+    p->log_n = t->log_n;
+    const size_t N = (size_t)1 << t->log_n, M = (size_t)L + K;
+    for (int d = 0; d < dnum; d++) {
+        const int lo = d * p->alpha, hi = std::min(L, lo + p->alpha);
+        if (lo >= hi) return fail(FHE_ERR_INVALID, "dnum leaves an empty digit");
+        std::vector<u64> in(t->q.begin() + lo, t->q.begin() + hi), other;
+        for (size_t j = 0; j < M; j++)
+            if ((int)j < lo || (int)j >= hi) other.push_back(t->q[j]);
+        fhe_baseconv *bc = nullptr;
+        int rc = fhe_baseconv_create(ctx, in.data(), (int)in.size(), other.data(), (int)other.size(), &bc);
+        if (rc) return rc;
+        p->up.push_back(bc);
+    }
+    {
+        std::vector<u64> P(t->q.begin() + L, t->q.begin() + M), Q(t->q.begin(), t->q.begin() + L);
+        int rc = fhe_baseconv_create(ctx, P.data(), K, Q.data(), L, &p->down);
+        if (rc) return rc;
+        std::vector<u64> pinv(L);
+        for (int j = 0; j < L; j++) {
+            u64 pm = 1 % Q[j];
+            for (u64 pk : P) pm = host::mul_mod(pm, pk % Q[j], Q[j]);
+            pinv[j] = host::inv_mod(pm, Q[j]);
+            if (!pinv[j]) return fail(FHE_ERR_INVALID, "special primes must be coprime to the ciphertext primes");
+        }
+        HIP_TRY(hipSetDevice(ctx->device));
+        HIP_TRY(p->pinv.upload(pinv));
+    }
+    HIP_TRY(p->coef.alloc(L * N * 8));
+    HIP_TRY(p->ext.alloc(M * N * 8));
+    HIP_TRY(p->tmp.alloc(M * N * 8));
+    HIP_TRY(p->acc0.alloc(M * N * 8));
+    HIP_TRY(p->acc1.alloc(M * N * 8));
+    HIP_TRY(p->tP.alloc((size_t)K * N * 8));
+    HIP_TRY(p->conv.alloc(L * N * 8));
+    *out = p.release();
+    return FHE_OK;
+}
+
+int fhe_keyswitch_destroy(fhe_keyswitch *p)
+{
+    if (p) {
+        (void)hipSetDevice(p->ctx->device);
+        delete p;
+    }
+    return FHE_OK;
+}
+
+int fhe_keyswitch_apply(fhe_ctx *ctx, fhe_keyswitch *p, uint64_t *d_out0, uint64_t *d_out1, const uint64_t *d_c,
+                        const uint64_t *d_evk, void *stream)
+{
+    if (!ctx || !p || !d_out0 || !d_out1 || !d_c || !d_evk) return fail(FHE_ERR_INVALID, "null argument");
+    HIP_TRY(hipSetDevice(ctx->device));
+    hipStream_t st = pick(ctx, stream);
+    const fhe_ntt_tables *t = p->t;
+    const size_t N = (size_t)1 << p->log_n, L = p->L, K = p->K, M = L + K;
+    u64 *coef = p->coef.as<u64>(), *ext = p->ext.as<u64>(), *tmp = p->tmp.as<u64>();
+    u64 *acc[2] = {p->acc0.as<u64>(), p->acc1.as<u64>()};
+    int rc;
+    // INTT of the L input limbs (the "3 INTT" that open KEYSWITCH in the L=4 trace, 16384_4:468-470)
+    HIP_TRY(hipMemcpyAsync(coef, d_c, L * N * 8, hipMemcpyDeviceToDevice, st));
+    if ((rc = ntt_batch(ctx, coef, t, 1, L, 0, st, true))) return rc;
+    HIP_TRY(hipMemsetAsync(acc[0], 0, M * N * 8, st));
+    HIP_TRY(hipMemsetAsync(acc[1], 0, M * N * 8, st));
+    for (int d = 0; d < p->dnum; d++) {
+        const size_t lo = (size_t)d * p->alpha, hi = std::min(L, lo + (size_t)p->alpha);
+        // base extension of the digit to every other prime (MODREDUCTION, 16384_4:471-452), coefficient domain
+        if ((rc = fhe_baseconv_exact(ctx, tmp, coef + lo * N, p->up[d], N, st))) return rc;
+        if (lo) HIP_TRY(hipMemcpyAsync(ext, tmp, lo * N * 8, hipMemcpyDeviceToDevice, st));
+        if (hi < M) HIP_TRY(hipMemcpyAsync(ext + hi * N, tmp + lo * N, (M - hi) * N * 8, hipMemcpyDeviceToDevice, st));
+        // NTT of the extended limbs; the digit's own limbs are already in NTT form in the input
+        if (lo && (rc = ntt_batch(ctx, ext, t, 1, lo, 0, st, false))) return rc;
+        if (hi < M && (rc = ntt_batch(ctx, ext + hi * N, t, 1, M - hi, hi, st, false))) return rc;
+        HIP_TRY(hipMemcpyAsync(ext + lo * N, d_c + lo * N, (hi - lo) * N * 8, hipMemcpyDeviceToDevice, st));
+        // multiply-accumulate with the evaluation key of this digit (MULTEVALK)
+        for (int h = 0; h < 2; h++) {
+            const u64 *key = d_evk + ((size_t)d * 2 + h) * M * N;
+            if ((rc = pointwise(ctx, acc[h], ext, key, t, 1, M, 0, st, true))) return rc;
+        }
+    }
+    // mod-down by P (MODSWITCH, 16384_4:454-463): INTT of the special limbs, conversion to Q, NTT, subtract, times P^-1
+    u64 *outs[2] = {d_out0, d_out1};
+    for (int h = 0; h < 2; h++) {
+        u64 *tP = p->tP.as<u64>(), *conv = p->conv.as<u64>();
+        HIP_TRY(hipMemcpyAsync(tP, acc[h] + L * N, K * N * 8, hipMemcpyDeviceToDevice, st));
+        if ((rc = ntt_batch(ctx, tP, t, 1, K, L, st, true))) return rc;
+        if ((rc = fhe_baseconv_exact(ctx, conv, tP, p->down, N, st))) return rc;
+        if ((rc = ntt_batch(ctx, conv, t, 1, L, 0, st, false))) return rc;
+        hipError_t e = launch_sub_scale(st, outs[h], acc[h], conv, p->pinv.as<u64>(), t->d_lp.as<LimbParams>(), 0, (u32)L, p->log_n);
+        if (e != hipSuccess) return hip_fail(e, "launch_sub_scale");
+    }
+    return FHE_OK;
 }
 
 // ---------------------------------------------------------------- base conversion

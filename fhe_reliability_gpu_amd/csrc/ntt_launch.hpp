@@ -41,6 +41,13 @@ hipError_t launch_bitrev_scale(hipStream_t st, u64 *dst, const u64 *src, int log
 hipError_t launch_fourstep_mid(hipStream_t st, u64 *out, const u64 *in, u32 rows, u32 cols, int log_cols,
                                const u64 *tw, const ModConst &mc, bool with_twiddle);
 hipError_t launch_transpose(hipStream_t st, u64 *out, const u64 *in, u32 rows, u32 cols);
+// out = (a - b) * scal[l] mod q_l over `limbs` limbs starting at table index limb0
+hipError_t launch_sub_scale(hipStream_t st, u64 *out, const u64 *a, const u64 *b, const u64 *scal, const LimbParams *lp, u32 limb0,
+                            u32 limbs, int logn);
+// Galois automorphism x -> x^k: coefficient domain (sign-aware scatter) and NTT domain (gather)
+hipError_t launch_automorphism(hipStream_t st, u64 *dst, const u64 *src, const LimbParams *lp, u32 limb0, u32 limbs, u32 units,
+                               int logn, u32 k);
+hipError_t launch_automorphism_ntt(hipStream_t st, u64 *dst, const u64 *src, u32 units, int logn, u32 k);
 
 // ---- baseconv_kernels.hip ------------------------------------------------------
 struct BaseConvPlanDev {

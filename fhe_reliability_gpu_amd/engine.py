@@ -376,3 +376,46 @@ def diag_block_hadamard_matvec(M_blocks, v, mod: int = 0, eng: Optional[Engine] 
     check(lib.fhe_bsgs_hadamard(eng._h, y.ptr, dM.ptr, dv.ptr, k, bs, mod, None))
     out = y.download()
     return out.view(np.int64) if mod == 0 else out
+
+
+# ---------------------------------------------------------------------------
+# Rotation / key switching
+# ---------------------------------------------------------------------------
+def automorphism(eng: Engine, t: NttTables, src: DeviceArray, galois_elt: int, n_poly: int = 1, limbs: Optional[int] = None,
+                 start: int = 0, ntt_domain: bool = False) -> DeviceArray:
+    """x -> x^galois_elt on every limb (coefficient domain, or NTT domain when ``ntt_domain``)."""
+    limbs = len(t) - start if limbs is None else limbs
+    dst = eng.alloc(src.size)
+    dst.shape = src.shape
+    if ntt_domain:
+        check(lib.fhe_automorphism_ntt(eng._h, dst.ptr, src.ptr, t.log_n, galois_elt, n_poly * limbs, None))
+    else:
+        check(lib.fhe_automorphism(eng._h, dst.ptr, src.ptr, t._h, galois_elt, n_poly, limbs, start, None))
+    return dst
+
+
+class KeySwitch:
+    """Hybrid RNS key switching over the primes of ``t`` (L ciphertext primes then K special primes,
+    ``dnum`` digits); operation sequence of the reference's SEAL trace
+    (profile_framewk/build/data/ckks/16384_4:466-539)."""
+
+    def __init__(self, eng: Engine, t: NttTables, L: int, K: int, dnum: int):
+        self.eng, self.t, self.L, self.K, self.dnum = eng, t, L, K, dnum
+        h = vp()
+        check(lib.fhe_keyswitch_create(eng._h, t._h, L, K, dnum, C.byref(h)))
+        self._h = h
+
+    def apply(self, c: DeviceArray, evk: DeviceArray, stream=None):
+        """c: [L][N] NTT domain; evk: [dnum][2][L+K][N] NTT domain -> (out0, out1), each [L][N] NTT domain."""
+        n = self.L * self.t.N
+        o0, o1 = self.eng.alloc(n), self.eng.alloc(n)
+        o0.shape = o1.shape = (self.L, self.t.N)
+        check(lib.fhe_keyswitch_apply(self.eng._h, self._h, o0.ptr, o1.ptr, c.ptr, evk.ptr, stream))
+        return o0, o1
+
+    def __del__(self):
+        try:
+            if self._h and self.eng._h:
+                lib.fhe_keyswitch_destroy(self._h)
+        except Exception:
+            pass

@@ -42,6 +42,7 @@ typedef struct fhe_ctx fhe_ctx;               /* device + stream (phantom::util:
 typedef struct fhe_ntt_tables fhe_ntt_tables; /* DModulus[] + DNTTTable (ntt_test.cu:47-69) */
 typedef struct fhe_baseconv fhe_baseconv;     /* base-conversion plan (rfhe_framewk/src/baseConv.py:14-18) */
 typedef struct fhe_fourstep fhe_fourstep;     /* four-step plan (reliability_test/four_step_ntt_prot.py:71-79) */
+typedef struct fhe_keyswitch fhe_keyswitch;   /* key-switch plan (shape of profile_framewk/build/data/ckks/16384_4:466-539) */
 
 int fhe_version(void);
 const char *fhe_last_error(void);
@@ -178,6 +179,29 @@ int fhe_crt_garner(fhe_ctx *ctx, uint64_t *d_x_lo, uint64_t *d_x_hi, const uint6
  * NumPy arithmetic); otherwise every product and the sum are reduced mod `mod`. */
 int fhe_bsgs_hadamard(fhe_ctx *ctx, uint64_t *d_y, const uint64_t *d_M_blocks, const uint64_t *d_v, int k,
                       int block_size, uint64_t mod, void *stream);
+
+/* ---- rotation / key switching ----------------------------------- */
+/* Galois automorphism x -> x^galois_elt (odd) -- the index map behind phantom::rotate_inplace
+ * (reliability_test/dotprod_test.cu:146) -- on coefficient-domain limbs: dst[(i k) mod N] = +-src[i].
+ * d_dst != d_src; layout [n_poly][limbs][N]. */
+int fhe_automorphism(fhe_ctx *ctx, uint64_t *d_dst, const uint64_t *d_src, const fhe_ntt_tables *t, uint32_t galois_elt,
+                     size_t n_poly, size_t limbs, size_t start_idx, void *stream);
+/* The same map on NTT-domain limbs (bit-reversed order): a pure permutation of the slots. */
+int fhe_automorphism_ntt(fhe_ctx *ctx, uint64_t *d_dst, const uint64_t *d_src, int log_n, uint32_t galois_elt, size_t n_units,
+                         void *stream);
+/* Hybrid RNS key switching with the operation sequence the reference's SEAL trace shows for one
+ * KEYSWITCH + MODSWITCH (profile_framewk/build/data/ckks/16384_4:466-539; summary in
+ * profile_framewk/build/sum_trace.py:10-94): INTT of the input limbs, per digit base extension to every
+ * other prime ("MODREDUCTION"), NTT, multiply-accumulate with the evaluation key ("MULTEVALK"), then
+ * mod-down by the special primes (INTT, conversion, NTT, subtract, times P^-1).
+ * `t` holds L ciphertext primes followed by K special primes; the L primes are cut into `dnum` digits of
+ * ceil(L/dnum) consecutive limbs (SEAL: dnum = L, one prime per digit; draw_dnum_rot_mul.py:64 sweeps dnum).
+ *   d_c   : L x N, NTT domain                       d_evk : dnum x 2 x (L+K) x N, NTT domain (b_d, a_d)
+ *   d_out0, d_out1 : L x N, NTT domain; out0 + out1*s ~ c*s' when evk encrypts P*Qhat_d*[Qhat_d^-1]_{Q_d}*s'. */
+int fhe_keyswitch_create(fhe_ctx *ctx, const fhe_ntt_tables *t, int L, int K, int dnum, fhe_keyswitch **out);
+int fhe_keyswitch_destroy(fhe_keyswitch *p);
+int fhe_keyswitch_apply(fhe_ctx *ctx, fhe_keyswitch *p, uint64_t *d_out0, uint64_t *d_out1, const uint64_t *d_c,
+                        const uint64_t *d_evk, void *stream);
 
 /* ---- fault injection ---------------------------------------------------------------- */
 /* _flip_bit_kernel<<<1,1>>> (reliability_test/dotprod_test.cu:31-33,55): data[idx] ^= 1 << bit */

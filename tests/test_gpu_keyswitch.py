@@ -1,0 +1,117 @@
+"""Rotation / key-switch composite on the GPU: word-for-word against the
+oracle-side restatement of the same sequence, and the algebraic property that defines key
+switching (big-integer check).  SEAL's own values are unavailable: "parity unpinned" there."""
+import random
+
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def F():
+    import fhe_reliability_gpu_amd as f
+    return f
+
+
+@pytest.fixture(scope="module")
+def eng(F):
+    return F.default_engine()
+
+
+def _poly_mul(a, b, q, logn):
+    from oracle import cport as O
+    psi = O.min_primitive_root(q, 2 << logn)
+    return O.polymul_ntt(np.asarray(a, dtype=np.uint64), np.asarray(b, dtype=np.uint64), psi, q)
+
+
+@pytest.mark.parametrize("logn", [4, 10, 13])
+@pytest.mark.parametrize("k", [3, 5, 2 * 16 - 1])
+def test_automorphism_coefficient_and_ntt_domain(F, eng, logn, k):
+    from oracle import cport as O
+    from oracle.keyswitch_ref import galois_coeff
+    N = 1 << logn
+    qs = F.create_moduli(N, [50, 61])
+    t = eng.tables(logn, qs)
+    rng = np.random.default_rng(logn * 100 + k)
+    a = np.stack([rng.integers(0, q, N, dtype=np.uint64) for q in qs])
+    want = np.stack([galois_coeff(a[l], k, q) for l, q in enumerate(qs)])
+    d = eng.upload(a)
+    assert (F.automorphism(eng, t, d, k).download() == want).all()
+    # NTT domain: sigma_k commutes with the transform
+    t.forward(d)
+    rot = F.automorphism(eng, t, d, k, ntt_domain=True)
+    t.inverse(rot)
+    assert (rot.download() == want).all()
+    # composition: sigma_k o sigma_k^-1 = id
+    kinv = pow(k, -1, 2 * N)
+    back = F.automorphism(eng, t, F.automorphism(eng, t, eng.upload(a), k), kinv)
+    assert (back.download() == a).all()
+
+
+@pytest.mark.parametrize("logn,L,K,dnum,bits", [(10, 4, 1, 4, 50), (10, 4, 2, 2, 50), (12, 6, 2, 3, 50), (13, 3, 2, 1, 61)])
+def test_keyswitch_matches_oracle_composite(F, eng, logn, L, K, dnum, bits):
+    from oracle.keyswitch_ref import keyswitch_ref
+    N, M = 1 << logn, L + K
+    qs = F.create_moduli(N, [bits] * L + [61] * K) if bits != 61 else F.create_moduli(N, [61] * M)
+    t = eng.tables(logn, qs)
+    rng = np.random.default_rng(logn + L * 7 + dnum)
+    c = np.stack([rng.integers(0, q, N, dtype=np.uint64) for q in qs[:L]])
+    evk = np.stack([np.stack([np.stack([rng.integers(0, q, N, dtype=np.uint64) for q in qs]) for _ in range(2)]) for _ in range(dnum)])
+    ks = F.KeySwitch(eng, t, L, K, dnum)
+    o0, o1 = ks.apply(eng.upload(c), eng.upload(evk))
+    w0, w1 = keyswitch_ref(c, evk, qs, L, K, dnum, logn)
+    assert (o0.download() == w0).all() and (o1.download() == w1).all()
+
+
+@pytest.mark.parametrize("L,K,dnum", [(4, 2, 2), (3, 1, 3)])
+def test_keyswitch_switches_keys(F, eng, L, K, dnum):
+    """out0 + out1*s = c*s' + small noise (mod Q) when evk_d = (-a_d s + e_d + P Qhat_d [Qhat_d^-1]_{Q_d} s', a_d)."""
+    from oracle import cport as O
+    logn, N, M = 10, 1024, L + K
+    qs = F.create_moduli(N, [50] * L + [61] * K)
+    Q, P = qs[:L], qs[L:]
+    Qprod, Pprod = int(np.prod([int(x) for x in Q], dtype=object)), int(np.prod([int(x) for x in P], dtype=object))
+    alpha = -(-L // dnum)
+    rnd = random.Random(42)
+    s = [rnd.choice((-1, 0, 1)) for _ in range(N)]
+    s2 = [rnd.choice((-1, 0, 1)) for _ in range(N)]
+    rps = [O.root_powers(q, logn) for q in qs]
+    res = lambda v, q: np.array([x % q for x in v], dtype=np.uint64)
+    evk = np.zeros((dnum, 2, M, N), dtype=np.uint64)
+    for d in range(dnum):
+        lo, hi = d * alpha, min(L, (d + 1) * alpha)
+        Qd = int(np.prod([int(x) for x in Q[lo:hi]], dtype=object))
+        Qhat = Qprod // Qd
+        Fd = Pprod * Qhat * pow(Qhat, -1, Qd)
+        e = [rnd.randint(-4, 4) for _ in range(N)]
+        for j, q in enumerate(qs):
+            a = np.array([rnd.randrange(q) for _ in range(N)], dtype=np.uint64)
+            a_s = _poly_mul(a, res(s, q), q, logn)
+            b = (res(e, q).astype(object) - a_s.astype(object) + (Fd % q) * res(s2, q).astype(object)) % q
+            evk[d, 0, j] = O.nwt_forward(b.astype(np.uint64), q, rps[j])
+            evk[d, 1, j] = O.nwt_forward(a, q, rps[j])
+    t = eng.tables(logn, qs)
+    c = np.stack([np.array([rnd.randrange(q) for _ in range(N)], dtype=np.uint64) for q in Q])        # coefficient domain
+    c_ntt = np.stack([O.nwt_forward(c[j], Q[j], rps[j]) for j in range(L)])
+    o0, o1 = F.KeySwitch(eng, t, L, K, dnum).apply(eng.upload(c_ntt), eng.upload(evk))
+    o0, o1 = o0.download(), o1.download()
+    # r_j = out0 + out1*s - c*s'  per prime, then CRT to a centred integer
+    r = []
+    for j, q in enumerate(Q):
+        x0 = O.nwt_inverse(o0[j], q, rps[j]).astype(object)
+        x1 = _poly_mul(O.nwt_inverse(o1[j], q, rps[j]), res(s, q), q, logn).astype(object)
+        cs = _poly_mul(c[j], res(s2, q), q, logn).astype(object)
+        r.append((x0 + x1 - cs) % q)
+    worst = 0
+    for i in range(N):
+        x = 0
+        for j, q in enumerate(Q):
+            Mj = Qprod // q
+            x += int(r[j][i]) * Mj * pow(Mj, -1, q)
+        x %= Qprod
+        if x > Qprod // 2:
+            x -= Qprod
+        worst = max(worst, abs(x))
+    assert worst < 8 * N, f"key-switch noise {worst} is not small (Q has {Qprod.bit_length()} bits)"
