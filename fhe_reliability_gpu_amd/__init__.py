@@ -9,6 +9,7 @@ not been built -- there is no CPU fallback.
 from . import _lib  # noqa: F401  (fails loudly when the HIP extension is missing)
 from ._lib import FheError  # noqa: F401
 from .engine import (  # noqa: F401
+    Abft,
     BaseConv,
     KeySwitch,
     automorphism,

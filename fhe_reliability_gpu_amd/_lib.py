@@ -79,6 +79,11 @@ _SIG = {
     "fhe_crt_garner": (ci, [vp, vp, vp, vp, p64, ci, sz, vp]),
     "fhe_bsgs_hadamard": (ci, [vp, vp, vp, vp, ci, ci, u64, vp]),
     "fhe_flip_bit": (ci, [vp, vp, u64, ci, vp]),
+    "fhe_abft_create": (ci, [vp, vp, C.POINTER(vp)]),
+    "fhe_abft_destroy": (ci, [vp]),
+    "fhe_abft_checksum": (ci, [vp, vp, ci, vp, vp, sz, sz, sz, vp]),
+    "fhe_ntt_forward_checked": (ci, [vp, vp, vp, vp, sz, sz, sz, vp, vp]),
+    "fhe_ctx_inject_fault": (ci, [vp, C.c_longlong, ci]),
     "fhe_automorphism": (ci, [vp, vp, vp, vp, C.c_uint32, sz, sz, sz, vp]),
     "fhe_automorphism_ntt": (ci, [vp, vp, vp, ci, C.c_uint32, sz, vp]),
     "fhe_keyswitch_create": (ci, [vp, vp, ci, ci, ci, C.POINTER(vp)]),

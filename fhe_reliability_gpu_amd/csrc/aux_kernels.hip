@@ -316,6 +316,56 @@ hipError_t launch_sub_scale(hipStream_t st, u64 *out, const u64 *a, const u64 *b
     return hipGetLastError();
 }
 
+// ---------------------------------------------------------------------------
+// ABFT: weighted checksum sum_i w_i x_i mod q (rfhe_framewk/src/negaclic_ntt.py:143-144), one
+// workgroup per limb-polynomial, lanes stride through the limb (coalesced), LDS tree reduction.
+// ---------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void k_weighted_checksum(u64 *out, const u64 *x, const u64 *w, const u64 *scal,
+                                                           const LimbParams *lp, u32 limb0, u32 limbs, u32 poly_stride, int logn)
+{
+    __shared__ u64 part[256];
+    const u32 unit = blockIdx.x, poly = unit / limbs, l = unit % limbs;
+    const LimbParams &p = lp[limb0 + l];
+    const u64 q = p.q, r0 = p.barrett_lo, r1 = p.barrett_hi;
+    const u64 *xs = x + (((u64)poly * poly_stride + l) << logn), *ws = w + ((u64)(limb0 + l) << logn);
+    u64 acc = 0;
+    for (u32 i = threadIdx.x; i < (1u << logn); i += 256) {
+        acc += mulmod_b(xs[i], ws[i], q, r0, r1);
+        acc = acc >= q ? acc - q : acc;
+    }
+    part[threadIdx.x] = acc;
+    __syncthreads();
+    for (u32 s = 128; s > 0; s >>= 1) {
+        if (threadIdx.x < s) {
+            u64 v = part[threadIdx.x] + part[threadIdx.x + s];
+            part[threadIdx.x] = v >= q ? v - q : v;
+        }
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) out[unit] = scal ? mulmod_b(part[0], scal[limb0 + l], q, r0, r1) : part[0];
+}
+
+hipError_t launch_weighted_checksum(hipStream_t st, u64 *out, const u64 *x, const u64 *w, const u64 *scal, const LimbParams *lp,
+                                    u32 limb0, u32 limbs, u32 units, u32 poly_stride, int logn)
+{
+    if (!units) return hipSuccess;
+    hipLaunchKernelGGL(k_weighted_checksum, dim3(units), dim3(256), 0, st, out, x, w, scal, lp, limb0, limbs, poly_stride, logn);
+    return hipGetLastError();
+}
+
+__global__ void k_compare_flags(u32 *flags, const u64 *a, const u64 *b, u32 units)
+{
+    const u32 i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < units) flags[i] = a[i] != b[i];
+}
+
+hipError_t launch_compare_flags(hipStream_t st, u32 *flags, const u64 *a, const u64 *b, u32 units)
+{
+    if (!units) return hipSuccess;
+    hipLaunchKernelGGL(k_compare_flags, dim3((units + 255) / 256), dim3(256), 0, st, flags, a, b, units);
+    return hipGetLastError();
+}
+
 // Galois automorphism x -> x^k (k odd) on coefficient-domain limbs: dst[(i k) mod N] = +-src[i]
 // (the index map behind phantom::rotate_inplace, reliability_test/dotprod_test.cu:146)
 __global__ __launch_bounds__(256) void k_automorphism(u64 *dst, const u64 *src, const LimbParams *lp, u32 limb0, u32 limbs,

@@ -98,11 +98,20 @@ struct fhe_ctx {
     int mode = 0;          // 0 = two launches per transform (default), 1 = fused launch (experimental)
     unsigned fused_dist = 4, fused_wgs = 768;
     unsigned fused_skip_teams = 0;
+    long long fault_idx = -1;   // one-shot mid-transform bit flip (fhe_ctx_inject_fault)
+    int fault_bit = 0;
     int geo = 1;           // column-tile geometry of the two-launch path (ntt_launch.hpp)
     int fused_variant = 7;   // handoff*2 + stream hint (ntt_launch.hpp); 7 = acquire + nt streaming
     // cyclic tables keyed by (log_n, mod, root, convention)
     std::map<std::tuple<int, u64, u64, int>, std::unique_ptr<fhe_ntt_tables>> cyclic;
     std::map<std::vector<u64>, std::unique_ptr<GarnerTables>> garner;
+};
+
+struct fhe_abft {
+    fhe_ctx *ctx = nullptr;
+    const fhe_ntt_tables *t = nullptr;
+    DevBuf w, what, ninv;       // count x N weights (input side / output side), N^-1 per limb
+    DevBuf sum_in, sum_out;     // scratch checksums (grown on demand)
 };
 
 struct fhe_keyswitch {
@@ -275,6 +284,12 @@ int ntt_batch(fhe_ctx *ctx, u64 *d, const fhe_ntt_tables *t, size_t n_poly, size
                 HIP_TRY(ctl->alloc(need * 2));
             }
             e = launch_ntt_fused(st, a, t->log_n, inverse, path, ctl->as<u32>(), ctx->fused_dist, ctx->fused_wgs, ctx->fused_variant, ctx->fused_skip_teams);
+        } else if (ctx->fault_idx >= 0 && t->log_n >= 13) {
+            // fault-injection hook: corrupt the intermediate between the two launches (one shot)
+            e = launch_ntt(st, a, t->log_n, inverse, path, ctx->geo, 0);
+            if (e == hipSuccess) e = launch_flip_bit(st, d, (u64)ctx->fault_idx, ctx->fault_bit);
+            if (e == hipSuccess) e = launch_ntt(st, a, t->log_n, inverse, path, ctx->geo, 1);
+            ctx->fault_idx = -1;
         } else {
             e = launch_ntt(st, a, t->log_n, inverse, path, ctx->geo);
         }
@@ -697,6 +712,90 @@ int fhe_polymul(fhe_ctx *ctx, uint64_t *c, uint64_t *a, uint64_t *b, const fhe_n
     if (b != a && (rc = ntt_batch(ctx, b, t, n_poly, limbs, start_idx, stream, false))) return rc;
     if ((rc = pointwise(ctx, c, a, b, t, n_poly, limbs, start_idx, stream, false))) return rc;
     return ntt_batch(ctx, c, t, n_poly, limbs, start_idx, stream, true);
+}
+
+// ---------------------------------------------------------------- ABFT detector
+int fhe_ctx_inject_fault(fhe_ctx *ctx, long long idx, int bit)
+{
+    if (!ctx || bit < 0 || bit > 63) return fail(FHE_ERR_INVALID, "bad fault");
+    ctx->fault_idx = idx;
+    ctx->fault_bit = bit;
+    return FHE_OK;
+}
+
+int fhe_abft_create(fhe_ctx *ctx, const fhe_ntt_tables *t, fhe_abft **out)
+{
+    if (!ctx || !t || !out) return fail(FHE_ERR_INVALID, "null argument");
+    std::unique_ptr<fhe_abft> a(new fhe_abft);
+    a->ctx = ctx;
+    a->t = t;
+    const size_t N = (size_t)1 << t->log_n;
+    const u64 p = (u64)1 << (t->log_n / 2);
+    std::vector<u64> w((size_t)t->count * N), u((size_t)t->count * N), ninv(t->count);
+    for (int l = 0; l < t->count; l++) {
+        const u64 q = t->q[l];
+        u64 *wl = w.data() + (size_t)l * N, *ul = u.data() + (size_t)l * N;
+        for (size_t i = 0; i < N; i++) wl[i] = ((i % p + 1) + (i / p + 1)) % q;      // generate_weights, negaclic_ntt.py:7-13
+        // w_hat = V^-T w = N^-1 * NTT(u),  u = (w_0, -w_{N-1}, ..., -w_1)   (psi^N = -1)
+        ul[0] = wl[0];
+        for (size_t i = 1; i < N; i++) ul[i] = wl[N - i] ? q - wl[N - i] : 0;
+        ninv[l] = host::inv_mod((u64)(N % q), q);
+        if (!ninv[l]) return fail(FHE_ERR_INVALID, "N is not invertible modulo a table modulus");
+    }
+    HIP_TRY(hipSetDevice(ctx->device));
+    HIP_TRY(a->w.upload(w));
+    HIP_TRY(a->what.upload(u));
+    HIP_TRY(a->ninv.upload(ninv));
+    int rc = ntt_batch(ctx, a->what.as<u64>(), t, 1, t->count, 0, nullptr, false);
+    if (rc) return rc;
+    HIP_TRY(hipStreamSynchronize(ctx->stream));
+    *out = a.release();
+    return FHE_OK;
+}
+
+int fhe_abft_destroy(fhe_abft *a)
+{
+    if (a) {
+        (void)hipSetDevice(a->ctx->device);
+        delete a;
+    }
+    return FHE_OK;
+}
+
+int fhe_abft_checksum(fhe_ctx *ctx, const fhe_abft *a, int side, const uint64_t *d_data, uint64_t *d_out, size_t n_poly,
+                      size_t limbs, size_t start_idx, void *stream)
+{
+    if (!ctx || !a || !d_data || !d_out || (side != 0 && side != 1)) return fail(FHE_ERR_INVALID, "bad checksum arguments");
+    int rc = check_range(a->t, n_poly, limbs, start_idx);
+    if (rc) return rc;
+    HIP_TRY(hipSetDevice(ctx->device));
+    hipError_t e = launch_weighted_checksum(pick(ctx, stream), d_out, d_data, side ? a->what.as<u64>() : a->w.as<u64>(),
+                                            side ? a->ninv.as<u64>() : nullptr, a->t->d_lp.as<LimbParams>(), (u32)start_idx,
+                                            (u32)limbs, (u32)(n_poly * limbs), (u32)limbs, a->t->log_n);
+    if (e != hipSuccess) return hip_fail(e, "launch_weighted_checksum");
+    return FHE_OK;
+}
+
+int fhe_ntt_forward_checked(fhe_ctx *ctx, uint64_t *d_data, const fhe_ntt_tables *t, const fhe_abft *a, size_t n_poly,
+                            size_t limbs, size_t start_idx, uint32_t *d_flags, void *stream)
+{
+    if (!ctx || !a || a->t != t || !d_flags) return fail(FHE_ERR_INVALID, "bad checked-transform arguments");
+    const size_t units = n_poly * limbs;
+    fhe_abft *m = const_cast<fhe_abft *>(a);
+    HIP_TRY(hipSetDevice(ctx->device));
+    hipStream_t st = pick(ctx, stream);
+    if (m->sum_in.bytes < units * 8) {
+        HIP_TRY(hipStreamSynchronize(st));
+        HIP_TRY(m->sum_in.alloc(units * 16));
+        HIP_TRY(m->sum_out.alloc(units * 16));
+    }
+    int rc;
+    if ((rc = fhe_abft_checksum(ctx, a, 0, d_data, m->sum_in.as<u64>(), n_poly, limbs, start_idx, st))) return rc;
+    if ((rc = ntt_batch(ctx, d_data, t, n_poly, limbs, start_idx, st, false))) return rc;
+    if ((rc = fhe_abft_checksum(ctx, a, 1, d_data, m->sum_out.as<u64>(), n_poly, limbs, start_idx, st))) return rc;
+    hipError_t e = launch_compare_flags(st, d_flags, m->sum_in.as<u64>(), m->sum_out.as<u64>(), (u32)units);
+    if (e != hipSuccess) return hip_fail(e, "launch_compare_flags");
+    return FHE_OK;
 }
 
 // ---------------------------------------------------------------- rotation / key switching

@@ -45,32 +45,35 @@ static hipError_t launch_pass(hipStream_t st, const PassArgs &a)
     return hipGetLastError();
 }
 
+// which: -1 = whole transform, 0 / 1 = only the first / second launch of a two-pass size (used by
+// the fault-injection hook that corrupts the intermediate between the passes)
 template <class A, int LOGN, bool INV, int GEO>
-static hipError_t launch_transform(hipStream_t st, const PassArgs &a)
+static hipError_t launch_transform(hipStream_t st, const PassArgs &a, int which)
 {
     typedef Passes<A, LOGN, INV, GEO> PS;
     if constexpr (!PS::G::TWO_PASS) {
+        if (which == 1) return hipSuccess;
         return launch_pass<typename PS::Single, LOGN, INV, false>(st, a);
     } else if constexpr (!INV) {
-        hipError_t e = launch_pass<typename PS::Col, LOGN, INV, true>(st, a);
-        if (e != hipSuccess) return e;
+        hipError_t e = which == 1 ? hipSuccess : launch_pass<typename PS::Col, LOGN, INV, true>(st, a);
+        if (e != hipSuccess || which == 0) return e;
         return launch_pass<typename PS::Row, LOGN, INV, false>(st, a);
     } else {
-        hipError_t e = launch_pass<typename PS::Row, LOGN, INV, false>(st, a);
-        if (e != hipSuccess) return e;
+        hipError_t e = which == 1 ? hipSuccess : launch_pass<typename PS::Row, LOGN, INV, false>(st, a);
+        if (e != hipSuccess || which == 0) return e;
         return launch_pass<typename PS::Col, LOGN, INV, true>(st, a);
     }
 }
 
 template <class A>
-static hipError_t launch_size(hipStream_t st, const PassArgs &a, int logn, bool inverse, int geo)
+static hipError_t launch_size(hipStream_t st, const PassArgs &a, int logn, bool inverse, int geo, int which)
 {
     if (logn == 16 && geo == 0)   // tuning: the wide-tile geometry is kept for 2^16 only
-        return inverse ? launch_transform<A, 16, true, 0>(st, a) : launch_transform<A, 16, false, 0>(st, a);
+        return inverse ? launch_transform<A, 16, true, 0>(st, a, which) : launch_transform<A, 16, false, 0>(st, a, which);
     switch (logn) {
 #define FHE_CASE(L)                                                        \
     case L:                                                                \
-        return inverse ? launch_transform<A, L, true, (L >= 13 ? 1 : 0)>(st, a) : launch_transform<A, L, false, (L >= 13 ? 1 : 0)>(st, a);
+        return inverse ? launch_transform<A, L, true, (L >= 13 ? 1 : 0)>(st, a, which) : launch_transform<A, L, false, (L >= 13 ? 1 : 0)>(st, a, which);
         FHE_CASE(1) FHE_CASE(2) FHE_CASE(3) FHE_CASE(4) FHE_CASE(5) FHE_CASE(6) FHE_CASE(7) FHE_CASE(8)
         FHE_CASE(9) FHE_CASE(10) FHE_CASE(11) FHE_CASE(12) FHE_CASE(13) FHE_CASE(14) FHE_CASE(15) FHE_CASE(16)
         FHE_CASE(17) FHE_CASE(18) FHE_CASE(19) FHE_CASE(20)
@@ -83,10 +86,10 @@ static hipError_t launch_size(hipStream_t st, const PassArgs &a, int logn, bool 
 // (Chunking large batches so that the second launch would find the first launch's output in the
 // Infinity Cache was measured and brings nothing: a 512 MiB batch runs at the HBM-streaming rate
 // either way, and splitting costs launches.  One launch pair per call.)
-hipError_t launch_ntt(hipStream_t st, const PassArgs &a, int logn, bool inverse, int path, int geo)
+hipError_t launch_ntt(hipStream_t st, const PassArgs &a, int logn, bool inverse, int path, int geo, int which)
 {
     if (a.units == 0) return hipSuccess;
-    return path == PATH_F64 ? launch_size<ArithF64>(st, a, logn, inverse, geo) : launch_size<ArithU64>(st, a, logn, inverse, geo);
+    return path == PATH_F64 ? launch_size<ArithF64>(st, a, logn, inverse, geo, which) : launch_size<ArithU64>(st, a, logn, inverse, geo, which);
 }
 
 } // namespace fhe

@@ -8,7 +8,8 @@ namespace fhe {
 
 // Batched in-place transform of a.units limbs of 2^logn points, all on `path`.
 // geo: 1 = 16-column tiles (default), 0 = widest column tile (kept for 2^16 tuning runs)
-hipError_t launch_ntt(hipStream_t st, const PassArgs &a, int logn, bool inverse, int path, int geo = 1);
+// which: -1 whole transform; 0 / 1 = only the first / second launch of a two-pass size
+hipError_t launch_ntt(hipStream_t st, const PassArgs &a, int logn, bool inverse, int path, int geo = 1, int which = -1);
 
 // ---- ntt_fused.hip: single-launch variant for two-pass sizes --------------------
 bool fused_supported(int logn);
@@ -44,6 +45,12 @@ hipError_t launch_transpose(hipStream_t st, u64 *out, const u64 *in, u32 rows, u
 // out = (a - b) * scal[l] mod q_l over `limbs` limbs starting at table index limb0
 hipError_t launch_sub_scale(hipStream_t st, u64 *out, const u64 *a, const u64 *b, const u64 *scal, const LimbParams *lp, u32 limb0,
                             u32 limbs, int logn);
+// out[unit] = sum_i w[limb][i] * x[unit][i] mod q_limb (one workgroup per limb-polynomial): the weighted
+// checksum of the reference's ECC (rfhe_framewk/src/negaclic_ntt.py:130-149); scal[limb] multiplies the sum
+hipError_t launch_weighted_checksum(hipStream_t st, u64 *out, const u64 *x, const u64 *w, const u64 *scal, const LimbParams *lp,
+                                    u32 limb0, u32 limbs, u32 units, u32 poly_stride, int logn);
+// flags[unit] = a[unit] != b[unit]
+hipError_t launch_compare_flags(hipStream_t st, u32 *flags, const u64 *a, const u64 *b, u32 units);
 // Galois automorphism x -> x^k: coefficient domain (sign-aware scatter) and NTT domain (gather)
 hipError_t launch_automorphism(hipStream_t st, u64 *dst, const u64 *src, const LimbParams *lp, u32 limb0, u32 limbs, u32 units,
                                int logn, u32 k);

@@ -419,3 +419,36 @@ class KeySwitch:
                 lib.fhe_keyswitch_destroy(self._h)
         except Exception:
             pass
+
+
+# ---------------------------------------------------------------------------
+# ABFT detector
+# ---------------------------------------------------------------------------
+class Abft:
+    """Weighted-checksum ECC around the forward NTT (rfhe_framewk/src/negaclic_ntt.py:130-149)."""
+
+    def __init__(self, eng: Engine, t: NttTables):
+        self.eng, self.t = eng, t
+        h = vp()
+        check(lib.fhe_abft_create(eng._h, t._h, C.byref(h)))
+        self._h = h
+
+    def checksum(self, d: DeviceArray, side: int, n_poly: int = 1, limbs: Optional[int] = None, start: int = 0) -> np.ndarray:
+        limbs = len(self.t) - start if limbs is None else limbs
+        out = self.eng.alloc(n_poly * limbs)
+        check(lib.fhe_abft_checksum(self.eng._h, self._h, side, d.ptr, out.ptr, n_poly, limbs, start, None))
+        return out.download()
+
+    def forward_checked(self, d: DeviceArray, n_poly: int = 1, limbs: Optional[int] = None, start: int = 0) -> np.ndarray:
+        """In-place forward NTT; returns the per-limb-polynomial fault flags."""
+        limbs = len(self.t) - start if limbs is None else limbs
+        flags = self.eng.alloc((n_poly * limbs + 1) // 2)      # uint32 flags packed in a u64 buffer
+        check(lib.fhe_ntt_forward_checked(self.eng._h, d.ptr, self.t._h, self._h, n_poly, limbs, start, flags.ptr, None))
+        return flags.download().view(np.uint32)[: n_poly * limbs]
+
+    def __del__(self):
+        try:
+            if self._h and self.eng._h:
+                lib.fhe_abft_destroy(self._h)
+        except Exception:
+            pass

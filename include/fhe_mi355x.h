@@ -42,6 +42,7 @@ typedef struct fhe_ctx fhe_ctx;               /* device + stream (phantom::util:
 typedef struct fhe_ntt_tables fhe_ntt_tables; /* DModulus[] + DNTTTable (ntt_test.cu:47-69) */
 typedef struct fhe_baseconv fhe_baseconv;     /* base-conversion plan (rfhe_framewk/src/baseConv.py:14-18) */
 typedef struct fhe_fourstep fhe_fourstep;     /* four-step plan (reliability_test/four_step_ntt_prot.py:71-79) */
+typedef struct fhe_abft fhe_abft;             /* checksum weights of the ECC detector (rfhe_framewk/src/negaclic_ntt.py:130-149) */
 typedef struct fhe_keyswitch fhe_keyswitch;   /* key-switch plan (shape of profile_framewk/build/data/ckks/16384_4:466-539) */
 
 int fhe_version(void);
@@ -202,6 +203,27 @@ int fhe_keyswitch_create(fhe_ctx *ctx, const fhe_ntt_tables *t, int L, int K, in
 int fhe_keyswitch_destroy(fhe_keyswitch *p);
 int fhe_keyswitch_apply(fhe_ctx *ctx, fhe_keyswitch *p, uint64_t *d_out0, uint64_t *d_out1, const uint64_t *d_c,
                         const uint64_t *d_evk, void *stream);
+
+/* ---- ABFT detector around the forward NTT ------------------------- */
+/* Weighted-checksum ECC of rfhe_framewk/src/negaclic_ntt.py:130-149: with weights w (generate_weights,
+ * :7-13: w[i] = (i % p + 1) + (i / p + 1), p = 2^floor(log_n / 2)) and w_hat = V^-T w, a correct
+ * transform satisfies sum_i w_i a_i = sum_j w_hat_j a_hat_j (mod q).  w_hat is obtained on the device
+ * from the forward transform itself: w_hat = N^-1 * NTT(w_0, -w_{N-1}, ..., -w_1), already in the
+ * engine's bit-reversed order.  One weight set per limb of `t`. */
+int fhe_abft_create(fhe_ctx *ctx, const fhe_ntt_tables *t, fhe_abft **out);
+int fhe_abft_destroy(fhe_abft *a);
+/* side 0: d_out[unit] = sum_i w_i x_i (input side); side 1: N^-1 sum_j w'_j x_j (output side) */
+int fhe_abft_checksum(fhe_ctx *ctx, const fhe_abft *a, int side, const uint64_t *d_data, uint64_t *d_out, size_t n_poly,
+                      size_t limbs, size_t start_idx, void *stream);
+/* Forward NTT with the detector around it: d_flags[unit] (uint32) = 1 where the two checksums differ,
+ * i.e. where a fault hit the transform of that limb-polynomial (faults already present in the input
+ * are, by construction, not flagged). */
+int fhe_ntt_forward_checked(fhe_ctx *ctx, uint64_t *d_data, const fhe_ntt_tables *t, const fhe_abft *a, size_t n_poly,
+                            size_t limbs, size_t start_idx, uint32_t *d_flags, void *stream);
+/* Test hook for the detector: XOR bit `bit` of word `idx` of the buffer BETWEEN the two launches of the
+ * next two-pass forward/inverse transform issued on this context (one shot; idx < 0 clears it).  This is
+ * the in-flight analogue of the host-side flips of reliability_test/ntt_test.cu:104-135. */
+int fhe_ctx_inject_fault(fhe_ctx *ctx, long long idx, int bit);
 
 /* ---- fault injection ---------------------------------------------------------------- */
 /* _flip_bit_kernel<<<1,1>>> (reliability_test/dotprod_test.cu:31-33,55): data[idx] ^= 1 << bit */

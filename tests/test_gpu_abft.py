@@ -1,0 +1,80 @@
+"""On-device ABFT detector: the reference's weighted-checksum ECC
+(rfhe_framewk/src/negaclic_ntt.py:130-149) around the GPU forward NTT, exercised with a bit flip
+injected between the two launches of the transform."""
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def F():
+    import fhe_reliability_gpu_amd as f
+    return f
+
+
+@pytest.fixture(scope="module")
+def eng(F):
+    return F.default_engine()
+
+
+def _ref_weights(n, logn):
+    p = 1 << (logn // 2)
+    return [(i % p + 1) + (i // p + 1) for i in range(n)]
+
+
+@pytest.mark.parametrize("logn,bits", [(10, 50), (14, 50), (16, 50), (14, 61)])
+def test_checksums_agree_with_reference_ecc(F, eng, logn, bits):
+    from oracle import pyport as P
+    from oracle import cport as O
+    N = 1 << logn
+    qs = F.create_moduli(N, [bits, bits])
+    t = eng.tables(logn, qs)
+    ab = F.Abft(eng, t)
+    rng = np.random.default_rng(logn)
+    a = np.stack([rng.integers(0, q, N, dtype=np.uint64) for q in qs])
+    d = eng.upload(a)
+    cin = ab.checksum(d, 0)
+    w = _ref_weights(N, logn)
+    for l, q in enumerate(qs):
+        assert int(cin[l]) == sum(wi * int(x) for wi, x in zip(w, a[l])) % q        # checksum (negaclic_ntt.py:143)
+    t.forward(d)
+    cout = ab.checksum(d, 1)
+    assert (cin == cout).all()                                                        # == checksum_hat (:144-145)
+    if logn == 10:
+        # w_hat as the reference computes it (:133-138), read at bit-reversed indices, gives the same output-side sum
+        q, psi = qs[0], t.psi[0]
+        w_pre = [wi * pow(pow(psi, -1, q), i, q) % q for i, wi in enumerate(w)]
+        w_hat = P.intt_nthroot(w_pre, pow(psi, 2, q), q)
+        a_hat = d.download()[0]
+        idx = [P.bit_reverse(j, logn) for j in range(N)]
+        assert sum(w_hat[idx[j]] * int(a_hat[j]) for j in range(N)) % q == int(cin[0])
+
+
+@pytest.mark.parametrize("bits", [50, 61])
+def test_detector_flags_only_the_limb_hit_in_flight(F, eng, bits):
+    from fhe_reliability_gpu_amd._lib import check, lib
+    logn, N, limbs, polys = 14, 1 << 14, 3, 4
+    qs = F.create_moduli(N, [bits] * limbs)
+    t = eng.tables(logn, qs)
+    ab = F.Abft(eng, t)
+    rng = np.random.default_rng(99)
+    data = np.stack([np.stack([rng.integers(0, q, N, dtype=np.uint64) for q in qs]) for _ in range(polys)])
+    # clean run: nothing flagged
+    d = eng.upload(data)
+    assert not ab.forward_checked(d, n_poly=polys).any()
+    clean = d.download()
+    # a flip between the two launches of the transform: exactly that limb-polynomial is flagged
+    for unit, word, bit in ((5, 1234, 7), (0, 0, 30), (11, N - 1, 3)):
+        d = eng.upload(data)
+        check(lib.fhe_ctx_inject_fault(eng._h, unit * N + word, bit))
+        flags = ab.forward_checked(d, n_poly=polys)
+        assert flags.tolist() == [1 if u == unit else 0 for u in range(polys * limbs)], (unit, flags)
+        out = d.download().reshape(polys * limbs, N)
+        bad = (out != clean.reshape(polys * limbs, N)).any(axis=1)
+        assert bad.tolist() == [u == unit for u in range(polys * limbs)]
+    # a fault already present in the INPUT is not a transform fault: consistent checksums, no flag
+    faulty = data.copy()
+    faulty[1, 2, 77] ^= np.uint64(1 << 5)
+    d = eng.upload(faulty)
+    assert not ab.forward_checked(d, n_poly=polys).any()
