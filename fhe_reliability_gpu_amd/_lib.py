@@ -89,6 +89,10 @@ _SIG = {
     "fhe_keyswitch_create": (ci, [vp, vp, ci, ci, ci, C.POINTER(vp)]),
     "fhe_keyswitch_destroy": (ci, [vp]),
     "fhe_keyswitch_apply": (ci, [vp, vp, vp, vp, vp, vp, vp]),
+    "fhe_rotate": (ci, [vp, vp, vp, vp, vp, vp, C.c_uint32, vp, vp]),
+    "fhe_modadd": (ci, [vp, vp, vp, vp, vp, sz, sz, sz, vp]),
+    "fhe_ctx_trace": (ci, [vp, ci]),
+    "fhe_ctx_trace_read": (ci, [vp, C.c_char_p, sz, C.POINTER(sz)]),
 }
 
 EXPORTS = tuple(_SIG)

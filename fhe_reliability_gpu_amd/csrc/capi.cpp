@@ -7,6 +7,7 @@
 #include <hip/hip_runtime.h>
 
 #include <algorithm>
+#include <chrono>
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
@@ -98,6 +99,8 @@ struct fhe_ctx {
     int mode = 0;          // 0 = two launches per transform (default), 1 = fused launch (experimental)
     unsigned fused_dist = 4, fused_wgs = 768;
     unsigned fused_skip_teams = 0;
+    bool trace_on = false;
+    std::string trace;          // collected trace text (fhe_ctx_trace)
     long long fault_idx = -1;   // one-shot mid-transform bit flip (fhe_ctx_inject_fault)
     int fault_bit = 0;
     int geo = 1;           // column-tile geometry of the two-launch path (ntt_launch.hpp)
@@ -121,7 +124,7 @@ struct fhe_keyswitch {
     std::vector<fhe_baseconv *> up;     // per digit: digit primes -> every other prime (ascending index)
     fhe_baseconv *down = nullptr;       // P -> Q
     DevBuf pinv;                        // P^-1 mod q_j, j < L
-    DevBuf coef, ext, tmp, acc0, acc1, tP, conv;
+    DevBuf coef, ext, tmp, acc0, acc1, tP, conv, rot;
     ~fhe_keyswitch()
     {
         for (auto *b : up) fhe_baseconv_destroy(b);
@@ -247,6 +250,35 @@ template <class F> int for_each_run(const fhe_ntt_tables *t, size_t limbs, size_
     return FHE_OK;
 }
 
+// Trace scope: when tracing is on, synchronises the stream at both ends and appends one line.
+struct TraceScope {
+    fhe_ctx *ctx;
+    hipStream_t st;
+    const char *tag;
+    bool frontend;
+    std::chrono::steady_clock::time_point t0;
+    TraceScope(fhe_ctx *c, hipStream_t s, const char *t, bool fe = false) : ctx(c), st(s), tag(t), frontend(fe)
+    {
+        if (!ctx->trace_on) return;
+        (void)hipStreamSynchronize(st);
+        if (frontend) ctx->trace += std::string("frontend: ") + tag + "\n";
+        t0 = std::chrono::steady_clock::now();
+    }
+    ~TraceScope()
+    {
+        if (!ctx->trace_on) return;
+        (void)hipStreamSynchronize(st);
+        const long long us = std::chrono::duration_cast<std::chrono::microseconds>(std::chrono::steady_clock::now() - t0).count();
+        char line[128];
+        // enclosing scopes use SEAL's own "<layer>: TAG[n microseconds]" spelling, which the reference's
+        // tools skip; only leaf steps are "[TAG] total cost" lines (as in profile_framewk/build/sample.txt)
+        if (frontend) std::snprintf(line, sizeof line, "frontend: %s[%lld microseconds]\n", tag, us);
+        else if (!std::strcmp(tag, "KEYSWITCH")) std::snprintf(line, sizeof line, "evaluator: %s[%lld microseconds]\n", tag, us);
+        else std::snprintf(line, sizeof line, "[%s] total cost %lld \xC2\xB5s\n", tag, us);
+        ctx->trace += line;
+    }
+};
+
 int check_range(const fhe_ntt_tables *t, size_t n_poly, size_t limbs, size_t start_idx)
 {
     if (!t) return fail(FHE_ERR_INVALID, "null tables");
@@ -266,6 +298,7 @@ int ntt_batch(fhe_ctx *ctx, u64 *d, const fhe_ntt_tables *t, size_t n_poly, size
     HIP_TRY(hipSetDevice(ctx->device));
     hipStream_t st = pick(ctx, stream);
     const size_t N = (size_t)1 << t->log_n;
+    TraceScope tr(ctx, st, "NTT");
     return for_each_run(t, limbs, start_idx, [&](size_t off, size_t len, int path) -> int {
         PassArgs a{d + off * N, t->d_lp.as<LimbParams>(), (u32)(start_idx + off), (u32)len, (u32)(n_poly * len), (u32)limbs};
         hipError_t e;
@@ -704,6 +737,19 @@ int fhe_modmul_acc(fhe_ctx *ctx, uint64_t *c, const uint64_t *a, const uint64_t 
     return pointwise(ctx, c, a, b, t, n_poly, limbs, start_idx, stream, true);
 }
 
+int fhe_modadd(fhe_ctx *ctx, uint64_t *c, const uint64_t *a, const uint64_t *b, const fhe_ntt_tables *t, size_t n_poly,
+               size_t limbs, size_t start_idx, void *stream)
+{
+    if (!ctx || !c || !a || !b) return fail(FHE_ERR_INVALID, "null argument");
+    int rc = check_range(t, n_poly, limbs, start_idx);
+    if (rc) return rc;
+    HIP_TRY(hipSetDevice(ctx->device));
+    PointwiseArgs p{c, a, b, t->d_lp.as<LimbParams>(), (u32)start_idx, (u32)limbs, (u32)(n_poly * limbs), (u32)limbs, t->log_n};
+    hipError_t e = launch_modadd(pick(ctx, stream), p);
+    if (e != hipSuccess) return hip_fail(e, "launch_modadd");
+    return FHE_OK;
+}
+
 int fhe_polymul(fhe_ctx *ctx, uint64_t *c, uint64_t *a, uint64_t *b, const fhe_ntt_tables *t, size_t n_poly, size_t limbs,
                 size_t start_idx, void *stream)
 {
@@ -868,6 +914,7 @@ int fhe_keyswitch_create(fhe_ctx *ctx, const fhe_ntt_tables *t, int L, int K, in
     HIP_TRY(p->acc1.alloc(M * N * 8));
     HIP_TRY(p->tP.alloc((size_t)K * N * 8));
     HIP_TRY(p->conv.alloc(L * N * 8));
+    HIP_TRY(p->rot.alloc(3 * (size_t)L * N * 8));
     *out = p.release();
     return FHE_OK;
 }
@@ -892,6 +939,7 @@ int fhe_keyswitch_apply(fhe_ctx *ctx, fhe_keyswitch *p, uint64_t *d_out0, uint64
     u64 *coef = p->coef.as<u64>(), *ext = p->ext.as<u64>(), *tmp = p->tmp.as<u64>();
     u64 *acc[2] = {p->acc0.as<u64>(), p->acc1.as<u64>()};
     int rc;
+    TraceScope tr_ks(ctx, st, "KEYSWITCH");
     // INTT of the L input limbs (the "3 INTT" that open KEYSWITCH in the L=4 trace, 16384_4:468-470)
     HIP_TRY(hipMemcpyAsync(coef, d_c, L * N * 8, hipMemcpyDeviceToDevice, st));
     if ((rc = ntt_batch(ctx, coef, t, 1, L, 0, st, true))) return rc;
@@ -900,6 +948,8 @@ int fhe_keyswitch_apply(fhe_ctx *ctx, fhe_keyswitch *p, uint64_t *d_out0, uint64
     for (int d = 0; d < p->dnum; d++) {
         const size_t lo = (size_t)d * p->alpha, hi = std::min(L, lo + (size_t)p->alpha);
         // base extension of the digit to every other prime (MODREDUCTION, 16384_4:471-452), coefficient domain
+        {
+        TraceScope tr_mr(ctx, st, "MODREDUCTION");
         if ((rc = fhe_baseconv_exact(ctx, tmp, coef + lo * N, p->up[d], N, st))) return rc;
         if (lo) HIP_TRY(hipMemcpyAsync(ext, tmp, lo * N * 8, hipMemcpyDeviceToDevice, st));
         if (hi < M) HIP_TRY(hipMemcpyAsync(ext + hi * N, tmp + lo * N, (M - hi) * N * 8, hipMemcpyDeviceToDevice, st));
@@ -907,13 +957,16 @@ int fhe_keyswitch_apply(fhe_ctx *ctx, fhe_keyswitch *p, uint64_t *d_out0, uint64
         if (lo && (rc = ntt_batch(ctx, ext, t, 1, lo, 0, st, false))) return rc;
         if (hi < M && (rc = ntt_batch(ctx, ext + hi * N, t, 1, M - hi, hi, st, false))) return rc;
         HIP_TRY(hipMemcpyAsync(ext + lo * N, d_c + lo * N, (hi - lo) * N * 8, hipMemcpyDeviceToDevice, st));
+        }
         // multiply-accumulate with the evaluation key of this digit (MULTEVALK)
+        TraceScope tr_mk(ctx, st, "MULTEVK");
         for (int h = 0; h < 2; h++) {
             const u64 *key = d_evk + ((size_t)d * 2 + h) * M * N;
             if ((rc = pointwise(ctx, acc[h], ext, key, t, 1, M, 0, st, true))) return rc;
         }
     }
     // mod-down by P (MODSWITCH, 16384_4:454-463): INTT of the special limbs, conversion to Q, NTT, subtract, times P^-1
+    TraceScope tr_ms(ctx, st, "MODSWITCH");
     u64 *outs[2] = {d_out0, d_out1};
     for (int h = 0; h < 2; h++) {
         u64 *tP = p->tP.as<u64>(), *conv = p->conv.as<u64>();
@@ -923,6 +976,47 @@ int fhe_keyswitch_apply(fhe_ctx *ctx, fhe_keyswitch *p, uint64_t *d_out0, uint64
         if ((rc = ntt_batch(ctx, conv, t, 1, L, 0, st, false))) return rc;
         hipError_t e = launch_sub_scale(st, outs[h], acc[h], conv, p->pinv.as<u64>(), t->d_lp.as<LimbParams>(), 0, (u32)L, p->log_n);
         if (e != hipSuccess) return hip_fail(e, "launch_sub_scale");
+    }
+    return FHE_OK;
+}
+
+int fhe_rotate(fhe_ctx *ctx, fhe_keyswitch *p, uint64_t *d_out0, uint64_t *d_out1, const uint64_t *d_c0, const uint64_t *d_c1,
+               uint32_t galois_elt, const uint64_t *d_galois_key, void *stream)
+{
+    if (!ctx || !p || !d_out0 || !d_out1 || !d_c0 || !d_c1 || !d_galois_key) return fail(FHE_ERR_INVALID, "null argument");
+    if (d_out0 == d_c0 || d_out1 == d_c1) return fail(FHE_ERR_INVALID, "rotate is out of place");
+    HIP_TRY(hipSetDevice(ctx->device));
+    hipStream_t st = pick(ctx, stream);
+    TraceScope tr(ctx, st, "ROTATE", true);
+    const size_t L = p->L, N = (size_t)1 << p->log_n;
+    u64 *sig1 = p->rot.as<u64>(), *k0 = sig1 + L * N, *k1 = k0 + L * N;
+    int rc;
+    // sigma on both parts: in the NTT domain a permutation of the slots
+    if ((rc = fhe_automorphism_ntt(ctx, d_out0, d_c0, p->log_n, galois_elt, L, st))) return rc;
+    if ((rc = fhe_automorphism_ntt(ctx, sig1, d_c1, p->log_n, galois_elt, L, st))) return rc;
+    // sigma(c1) is a ciphertext part under sigma(s): switch it back to s with the Galois key
+    if ((rc = fhe_keyswitch_apply(ctx, p, k0, k1, sig1, d_galois_key, st))) return rc;
+    if ((rc = fhe_modadd(ctx, d_out0, d_out0, k0, p->t, 1, L, 0, st))) return rc;
+    HIP_TRY(hipMemcpyAsync(d_out1, k1, L * N * 8, hipMemcpyDeviceToDevice, st));
+    return FHE_OK;
+}
+
+int fhe_ctx_trace(fhe_ctx *ctx, int enable)
+{
+    if (!ctx) return fail(FHE_ERR_INVALID, "null ctx");
+    ctx->trace_on = enable != 0;
+    if (enable) ctx->trace.clear();
+    return FHE_OK;
+}
+
+int fhe_ctx_trace_read(fhe_ctx *ctx, char *buf, size_t cap, size_t *len)
+{
+    if (!ctx || (!buf && cap)) return fail(FHE_ERR_INVALID, "null argument");
+    if (len) *len = ctx->trace.size();
+    if (cap) {
+        const size_t n = std::min(cap - 1, ctx->trace.size());
+        std::memcpy(buf, ctx->trace.data(), n);
+        buf[n] = 0;
     }
     return FHE_OK;
 }

@@ -29,6 +29,7 @@ struct PointwiseArgs {
 };
 // c = a*b mod q (accumulate = false) or c = (c + a*b) mod q (accumulate = true), per limb
 hipError_t launch_modmul(hipStream_t st, const PointwiseArgs &p, bool accumulate);
+hipError_t launch_modadd(hipStream_t st, const PointwiseArgs &p);
 // data[idx] ^= 1 << bit  (reliability_test/dotprod_test.cu:31-33)
 hipError_t launch_flip_bit(hipStream_t st, u64 *data, u64 idx, int bit);
 // modulus + floor(2^128/q) for the Barrett helpers, passed by value

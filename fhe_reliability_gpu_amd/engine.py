@@ -42,6 +42,17 @@ class Engine:
         """``ntt_mode`` (0 two launches / 1 fused), ``fused_dist``, ``fused_wgs`` -- tuning only."""
         check(lib.fhe_ctx_set_option(self._h, name.encode(), int(value)))
 
+    def trace(self, enable: bool = True):
+        """Start (and clear) / stop the operation trace (profile_framewk trace-line format)."""
+        check(lib.fhe_ctx_trace(self._h, 1 if enable else 0))
+
+    def trace_text(self) -> str:
+        n = C.c_size_t()
+        check(lib.fhe_ctx_trace_read(self._h, None, 0, C.byref(n)))
+        buf = C.create_string_buffer(n.value + 1)
+        check(lib.fhe_ctx_trace_read(self._h, buf, n.value + 1, None))
+        return buf.value.decode("utf-8")
+
     def check(self):
         """Synchronise and raise if a fused-NTT launch reported a timed-out wait."""
         check(lib.fhe_ctx_check(self._h))
@@ -411,6 +422,14 @@ class KeySwitch:
         o0, o1 = self.eng.alloc(n), self.eng.alloc(n)
         o0.shape = o1.shape = (self.L, self.t.N)
         check(lib.fhe_keyswitch_apply(self.eng._h, self._h, o0.ptr, o1.ptr, c.ptr, evk.ptr, stream))
+        return o0, o1
+
+    def rotate(self, c0: DeviceArray, c1: DeviceArray, galois_elt: int, galois_key: DeviceArray, stream=None):
+        """``rotate_inplace`` (dotprod_test.cu:146) / frontend ROTATE of the SEAL traces: (c0, c1) -> (out0, out1)."""
+        n = self.L * self.t.N
+        o0, o1 = self.eng.alloc(n), self.eng.alloc(n)
+        o0.shape = o1.shape = (self.L, self.t.N)
+        check(lib.fhe_rotate(self.eng._h, self._h, o0.ptr, o1.ptr, c0.ptr, c1.ptr, galois_elt, galois_key.ptr, stream))
         return o0, o1
 
     def __del__(self):

@@ -150,6 +150,9 @@ int fhe_modmul(fhe_ctx *ctx, uint64_t *d_c, const uint64_t *d_a, const uint64_t 
 /* c = (c + a*b) mod q: keyswitch / BSGS inner-product accumulate (motivation/bsgs.py:50) */
 int fhe_modmul_acc(fhe_ctx *ctx, uint64_t *d_c, const uint64_t *d_a, const uint64_t *d_b, const fhe_ntt_tables *t,
                    size_t n_poly, size_t limbs, size_t start_idx, void *stream);
+/* c = (a + b) mod q per limb (phantom::add_inplace, reliability_test/dotprod_test.cu:147) */
+int fhe_modadd(fhe_ctx *ctx, uint64_t *d_c, const uint64_t *d_a, const uint64_t *d_b, const fhe_ntt_tables *t, size_t n_poly,
+               size_t limbs, size_t start_idx, void *stream);
 /* poly_mul_negacyclic_ntt (rfhe_framewk/src/negaclic_ntt.py:123-127): c = a * b mod (x^N + 1, q).
  * a and b are overwritten with their transforms (as the NTT-domain ciphertexts of the
  * reference stay transformed); c may alias a. */
@@ -203,6 +206,22 @@ int fhe_keyswitch_create(fhe_ctx *ctx, const fhe_ntt_tables *t, int L, int K, in
 int fhe_keyswitch_destroy(fhe_keyswitch *p);
 int fhe_keyswitch_apply(fhe_ctx *ctx, fhe_keyswitch *p, uint64_t *d_out0, uint64_t *d_out1, const uint64_t *d_c,
                         const uint64_t *d_evk, void *stream);
+
+/* Rotation of a two-part ciphertext (c0, c1), NTT domain, L limbs each -- phantom::rotate_inplace
+ * (dotprod_test.cu:146), frontend "ROTATE" of the reference's traces (16384_4:466-539): apply
+ * x -> x^galois_elt to both parts, key-switch the second part with the Galois key, add.
+ * out0 + out1*s ~ sigma(c0 + c1*s). */
+int fhe_rotate(fhe_ctx *ctx, fhe_keyswitch *p, uint64_t *d_out0, uint64_t *d_out1, const uint64_t *d_c0, const uint64_t *d_c1,
+               uint32_t galois_elt, const uint64_t *d_galois_key, void *stream);
+/* Operation trace in the line format the reference's tools consume
+ * (profile_framewk/build/analyze_trace.py:16-19, sum_trace.py:16-19): "frontend: ROTATE",
+ * "[NTT] total cost <n> us" per transform launch, "[MODREDUCTION]/[MULTEVK]/[KEYSWITCH]/[MODSWITCH] total
+ * cost <n> us" (inclusive of the transforms before them, as SEAL's timers are), "frontend: ROTATE[<n>
+ * microseconds]".  While enabled every traced step synchronises the stream (timing tool, not a fast
+ * path).  fhe_ctx_trace_read copies the text collected so far (NUL-terminated, truncated to `cap`) and
+ * returns its full length through *len. */
+int fhe_ctx_trace(fhe_ctx *ctx, int enable);
+int fhe_ctx_trace_read(fhe_ctx *ctx, char *buf, size_t cap, size_t *len);
 
 /* ---- ABFT detector around the forward NTT ------------------------- */
 /* Weighted-checksum ECC of rfhe_framewk/src/negaclic_ntt.py:130-149: with weights w (generate_weights,

@@ -115,3 +115,80 @@ def test_keyswitch_switches_keys(F, eng, L, K, dnum):
             x -= Qprod
         worst = max(worst, abs(x))
     assert worst < 8 * N, f"key-switch noise {worst} is not small (Q has {Qprod.bit_length()} bits)"
+
+
+def test_rotate_and_trace_format(F, eng):
+    """ROTATE composite: decrypt(rotate(ct)) = sigma(decrypt(ct)) up to key-switch noise, and the trace it
+    emits parses with the patterns of the reference's profile_framewk/build/sum_trace.py:16-19."""
+    import re
+    from oracle import cport as O
+    from oracle.keyswitch_ref import galois_coeff
+    logn, N, L, K, dnum, k = 10, 1024, 4, 2, 2, 5
+    M = L + K
+    qs = F.create_moduli(N, [50] * L + [61] * K)
+    Q, P = qs[:L], qs[L:]
+    Qprod = int(np.prod([int(x) for x in Q], dtype=object))
+    Pprod = int(np.prod([int(x) for x in P], dtype=object))
+    alpha = -(-L // dnum)
+    rnd = random.Random(7)
+    s = [rnd.choice((-1, 0, 1)) for _ in range(N)]
+    rps = [O.root_powers(q, logn) for q in qs]
+    res = lambda v, q: np.array([x % q for x in v], dtype=np.uint64)
+    # sigma(s) as signed coefficients
+    sig_s = [0] * N
+    for i, v in enumerate(s):
+        j = (i * k) % (2 * N)
+        if j >= N:
+            sig_s[j - N] = -v
+        else:
+            sig_s[j] = v
+    gk = np.zeros((dnum, 2, M, N), dtype=np.uint64)          # Galois key: switches sigma(s) -> s
+    for d in range(dnum):
+        lo, hi = d * alpha, min(L, (d + 1) * alpha)
+        Qd = int(np.prod([int(x) for x in Q[lo:hi]], dtype=object))
+        Qhat = Qprod // Qd
+        Fd = Pprod * Qhat * pow(Qhat, -1, Qd)
+        e = [rnd.randint(-4, 4) for _ in range(N)]
+        for j, q in enumerate(qs):
+            a = np.array([rnd.randrange(q) for _ in range(N)], dtype=np.uint64)
+            a_s = _poly_mul(a, res(s, q), q, logn)
+            b = (res(e, q).astype(object) - a_s.astype(object) + (Fd % q) * res(sig_s, q).astype(object)) % q
+            gk[d, 0, j] = O.nwt_forward(b.astype(np.uint64), q, rps[j])
+            gk[d, 1, j] = O.nwt_forward(a, q, rps[j])
+    # a "ciphertext": c1 random, c0 = m - c1*s  (so c0 + c1*s = m exactly)
+    m = [rnd.randrange(1 << 30) for _ in range(N)]
+    c1 = np.stack([np.array([rnd.randrange(q) for _ in range(N)], dtype=np.uint64) for q in Q])
+    c0 = np.stack([((res(m, q).astype(object) - _poly_mul(c1[j], res(s, q), q, logn).astype(object)) % q).astype(np.uint64)
+                   for j, q in enumerate(Q)])
+    t = eng.tables(logn, qs)
+    ks = F.KeySwitch(eng, t, L, K, dnum)
+    d0 = eng.upload(np.stack([O.nwt_forward(c0[j], Q[j], rps[j]) for j in range(L)]))
+    d1 = eng.upload(np.stack([O.nwt_forward(c1[j], Q[j], rps[j]) for j in range(L)]))
+    eng.trace(True)
+    o0, o1 = ks.rotate(d0, d1, k, eng.upload(gk))
+    eng.trace(False)
+    text = eng.trace_text()
+    o0, o1 = o0.download(), o1.download()
+    want = [int(x) for x in galois_coeff(np.array(m, dtype=np.uint64), k, 1 << 62)]          # sigma(m), entries m_i or 2^62 - m_i
+    want = [w if w < (1 << 61) else w - (1 << 62) for w in want]
+    worst = 0
+    for j, q in enumerate(Q[:1]):                                    # noise is tiny: one prime suffices to see it
+        x0 = O.nwt_inverse(o0[j], q, rps[j]).astype(object)
+        x1 = _poly_mul(O.nwt_inverse(o1[j], q, rps[j]), res(s, q), q, logn).astype(object)
+        dec = (x0 + x1) % q
+        for i in range(N):
+            diff = (int(dec[i]) - want[i]) % q
+            diff = diff - q if diff > q // 2 else diff
+            worst = max(worst, abs(diff))
+    assert worst < 8 * N, worst
+    # trace format (sum_trace.py: start_re, end_re, ntt_re, cost_re)
+    lines = text.strip().split("\n")
+    assert re.match(r"^frontend: ROTATE$", lines[0])
+    assert re.match(r"^frontend: ROTATE\[(\d+)\s+microseconds\]$", lines[-1])
+    assert sum(1 for l in lines if re.match(r"^evaluator: KEYSWITCH\[\d+ microseconds\]$", l)) == 1
+    leaf = [l for l in lines[1:-1] if not l.startswith("evaluator:")]
+    tags = [re.match(r"^\[([^\]]+)\] total cost\s+(\d+)\s+µs", l).group(1) for l in leaf]
+    assert tags.count("MODREDUCTION") == dnum and tags.count("MULTEVK") == dnum and tags.count("MODSWITCH") == 1
+    assert set(tags) == {"NTT", "MODREDUCTION", "MULTEVK", "MODSWITCH"}      # the tag set of profile_framewk/build/sample.txt
+    # 1 INTT batch + per digit 2 NTT batches (limbs below / above the digit; one is empty at the edges) + 2 x (INTT + NTT) in mod-down
+    assert tags.count("NTT") == 1 + sum((1 if d * alpha else 0) + 1 for d in range(dnum)) + 4
