@@ -91,6 +91,9 @@ _SIG = {
     "fhe_keyswitch_apply": (ci, [vp, vp, vp, vp, vp, vp, vp]),
     "fhe_rotate": (ci, [vp, vp, vp, vp, vp, vp, C.c_uint32, vp, vp]),
     "fhe_modadd": (ci, [vp, vp, vp, vp, vp, sz, sz, sz, vp]),
+    "fhe_modsub": (ci, [vp, vp, vp, vp, vp, sz, sz, sz, vp]),
+    "fhe_scalar_affine": (ci, [vp, vp, vp, p64, p64, vp, sz, sz, sz, vp]),
+    "fhe_keyswitch_set_plain_modulus": (ci, [vp, u64]),
     "fhe_ctx_trace": (ci, [vp, ci]),
     "fhe_ctx_trace_read": (ci, [vp, C.c_char_p, sz, C.POINTER(sz)]),
 }

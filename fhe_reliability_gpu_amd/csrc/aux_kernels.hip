@@ -90,6 +90,56 @@ hipError_t launch_modadd(hipStream_t st, const PointwiseArgs &p)
     return hipGetLastError();
 }
 
+// c = (a - b) mod q per limb
+__global__ __launch_bounds__(256) void k_modsub(PointwiseArgs p)
+{
+    const u64 n = (u64)1 << p.logn;
+    const u64 total = (u64)p.units << p.logn;
+    for (u64 i_ = blockIdx.x * (u64)blockDim.x + threadIdx.x; i_ < total; i_ += (u64)gridDim.x * blockDim.x) {
+        const u32 unit = (u32)(i_ >> p.logn);
+        const u32 poly = unit / p.limbs, l = unit % p.limbs;
+        const LimbParams &lp = p.lp[p.limb0 + l];
+        const u64 q = lp.q, r0 = lp.barrett_lo, r1 = lp.barrett_hi;
+        const u64 i = (((u64)poly * p.poly_stride + l) << p.logn) + (i_ & (n - 1));
+        const u64 x = barrett128(p.a[i], 0, q, r0, r1), y = barrett128(p.b[i], 0, q, r0, r1);
+        p.c[i] = x >= y ? x - y : x + q - y;
+    }
+}
+
+hipError_t launch_modsub(hipStream_t st, const PointwiseArgs &p)
+{
+    const u64 total = (u64)p.units << p.logn;
+    if (!total) return hipSuccess;
+    u64 want = (total + 255) / 256;
+    hipLaunchKernelGGL(k_modsub, dim3((u32)(want > 8192 ? 8192 : want)), dim3(256), 0, st, p);
+    return hipGetLastError();
+}
+
+// c = a * s_l + t_l mod q_l with per-limb scalars passed by value (scalar multiply / scalar add)
+__global__ __launch_bounds__(256) void k_scalar_affine(PointwiseArgs p, ScalarVec mul, ScalarVec add)
+{
+    const u64 n = (u64)1 << p.logn;
+    const u64 total = (u64)p.units << p.logn;
+    for (u64 i_ = blockIdx.x * (u64)blockDim.x + threadIdx.x; i_ < total; i_ += (u64)gridDim.x * blockDim.x) {
+        const u32 unit = (u32)(i_ >> p.logn);
+        const u32 poly = unit / p.limbs, l = unit % p.limbs;
+        const LimbParams &lp = p.lp[p.limb0 + l];
+        const u64 q = lp.q, r0 = lp.barrett_lo, r1 = lp.barrett_hi;
+        const u64 i = (((u64)poly * p.poly_stride + l) << p.logn) + (i_ & (n - 1));
+        u64 v = mulmod_b(p.a[i], mul.v[l], q, r0, r1) + add.v[l];
+        p.c[i] = v >= q ? v - q : v;
+    }
+}
+
+hipError_t launch_scalar_affine(hipStream_t st, const PointwiseArgs &p, const ScalarVec &mul, const ScalarVec &add)
+{
+    const u64 total = (u64)p.units << p.logn;
+    if (!total) return hipSuccess;
+    u64 want = (total + 255) / 256;
+    hipLaunchKernelGGL(k_scalar_affine, dim3((u32)(want > 8192 ? 8192 : want)), dim3(256), 0, st, p, mul, add);
+    return hipGetLastError();
+}
+
 hipError_t launch_modmul(hipStream_t st, const PointwiseArgs &p, bool accumulate)
 {
     const u64 total = (u64)p.units << p.logn;

@@ -121,6 +121,8 @@ struct fhe_keyswitch {
     fhe_ctx *ctx = nullptr;
     const fhe_ntt_tables *t = nullptr;
     int L = 0, K = 0, dnum = 0, alpha = 0, log_n = 0;
+    u64 plain_modulus = 0;              // BGV: delta must vanish modulo this (0 = CKKS-style flooring)
+    std::vector<u64> t_inv_P, t_mod_Q;  // plain_modulus^-1 mod p_k, plain_modulus mod q_j
     std::vector<fhe_baseconv *> up;     // per digit: digit primes -> every other prime (ascending index)
     fhe_baseconv *down = nullptr;       // P -> Q
     DevBuf pinv;                        // P^-1 mod q_j, j < L
@@ -750,6 +752,39 @@ int fhe_modadd(fhe_ctx *ctx, uint64_t *c, const uint64_t *a, const uint64_t *b, 
     return FHE_OK;
 }
 
+int fhe_modsub(fhe_ctx *ctx, uint64_t *c, const uint64_t *a, const uint64_t *b, const fhe_ntt_tables *t, size_t n_poly,
+               size_t limbs, size_t start_idx, void *stream)
+{
+    if (!ctx || !c || !a || !b) return fail(FHE_ERR_INVALID, "null argument");
+    int rc = check_range(t, n_poly, limbs, start_idx);
+    if (rc) return rc;
+    HIP_TRY(hipSetDevice(ctx->device));
+    PointwiseArgs p{c, a, b, t->d_lp.as<LimbParams>(), (u32)start_idx, (u32)limbs, (u32)(n_poly * limbs), (u32)limbs, t->log_n};
+    hipError_t e = launch_modsub(pick(ctx, stream), p);
+    if (e != hipSuccess) return hip_fail(e, "launch_modsub");
+    return FHE_OK;
+}
+
+int fhe_scalar_affine(fhe_ctx *ctx, uint64_t *c, const uint64_t *a, const uint64_t *mul, const uint64_t *add, const fhe_ntt_tables *t,
+                      size_t n_poly, size_t limbs, size_t start_idx, void *stream)
+{
+    if (!ctx || !c || !a) return fail(FHE_ERR_INVALID, "null argument");
+    if (limbs > SCALAR_MAX_LIMBS) return fail(FHE_ERR_UNSUPPORTED, "at most 64 limbs per scalar call");
+    int rc = check_range(t, n_poly, limbs, start_idx);
+    if (rc) return rc;
+    ScalarVec m{}, ad{};
+    for (size_t l = 0; l < limbs; l++) {
+        const u64 q = t->q[start_idx + l];
+        m.v[l] = mul ? mul[l] % q : 1 % q;
+        ad.v[l] = add ? add[l] % q : 0;
+    }
+    HIP_TRY(hipSetDevice(ctx->device));
+    PointwiseArgs p{c, a, a, t->d_lp.as<LimbParams>(), (u32)start_idx, (u32)limbs, (u32)(n_poly * limbs), (u32)limbs, t->log_n};
+    hipError_t e = launch_scalar_affine(pick(ctx, stream), p, m, ad);
+    if (e != hipSuccess) return hip_fail(e, "launch_scalar_affine");
+    return FHE_OK;
+}
+
 int fhe_polymul(fhe_ctx *ctx, uint64_t *c, uint64_t *a, uint64_t *b, const fhe_ntt_tables *t, size_t n_poly, size_t limbs,
                 size_t start_idx, void *stream)
 {
@@ -919,6 +954,23 @@ int fhe_keyswitch_create(fhe_ctx *ctx, const fhe_ntt_tables *t, int L, int K, in
     return FHE_OK;
 }
 
+int fhe_keyswitch_set_plain_modulus(fhe_keyswitch *p, uint64_t plain_modulus)
+{
+    if (!p) return fail(FHE_ERR_INVALID, "null plan");
+    p->plain_modulus = plain_modulus;
+    p->t_inv_P.clear();
+    p->t_mod_Q.clear();
+    if (plain_modulus) {
+        for (int k = 0; k < p->K; k++) {
+            const u64 pk = p->t->q[p->L + k], inv = host::inv_mod(plain_modulus % pk, pk);
+            if (!inv) return fail(FHE_ERR_INVALID, "plain modulus must be coprime to the special primes");
+            p->t_inv_P.push_back(inv);
+        }
+        for (int j = 0; j < p->L; j++) p->t_mod_Q.push_back(plain_modulus % p->t->q[j]);
+    }
+    return FHE_OK;
+}
+
 int fhe_keyswitch_destroy(fhe_keyswitch *p)
 {
     if (p) {
@@ -972,7 +1024,10 @@ int fhe_keyswitch_apply(fhe_ctx *ctx, fhe_keyswitch *p, uint64_t *d_out0, uint64
         u64 *tP = p->tP.as<u64>(), *conv = p->conv.as<u64>();
         HIP_TRY(hipMemcpyAsync(tP, acc[h] + L * N, K * N * 8, hipMemcpyDeviceToDevice, st));
         if ((rc = ntt_batch(ctx, tP, t, 1, K, L, st, true))) return rc;
+        // BGV: remove delta = t * [acc * t^-1]_P instead of [acc]_P, so that delta = 0 mod t
+        if (p->plain_modulus && (rc = fhe_scalar_affine(ctx, tP, tP, p->t_inv_P.data(), nullptr, t, 1, K, L, st))) return rc;
         if ((rc = fhe_baseconv_exact(ctx, conv, tP, p->down, N, st))) return rc;
+        if (p->plain_modulus && (rc = fhe_scalar_affine(ctx, conv, conv, p->t_mod_Q.data(), nullptr, t, 1, L, 0, st))) return rc;
         if ((rc = ntt_batch(ctx, conv, t, 1, L, 0, st, false))) return rc;
         hipError_t e = launch_sub_scale(st, outs[h], acc[h], conv, p->pinv.as<u64>(), t->d_lp.as<LimbParams>(), 0, (u32)L, p->log_n);
         if (e != hipSuccess) return hip_fail(e, "launch_sub_scale");

@@ -30,6 +30,13 @@ struct PointwiseArgs {
 // c = a*b mod q (accumulate = false) or c = (c + a*b) mod q (accumulate = true), per limb
 hipError_t launch_modmul(hipStream_t st, const PointwiseArgs &p, bool accumulate);
 hipError_t launch_modadd(hipStream_t st, const PointwiseArgs &p);
+hipError_t launch_modsub(hipStream_t st, const PointwiseArgs &p);
+constexpr int SCALAR_MAX_LIMBS = 64;
+struct ScalarVec {
+    u64 v[SCALAR_MAX_LIMBS];
+};
+// c = a * mul[l] + add[l] mod q_l (per-limb scalars, reduced by the caller)
+hipError_t launch_scalar_affine(hipStream_t st, const PointwiseArgs &p, const ScalarVec &mul, const ScalarVec &add);
 // data[idx] ^= 1 << bit  (reliability_test/dotprod_test.cu:31-33)
 hipError_t launch_flip_bit(hipStream_t st, u64 *data, u64 idx, int bit);
 // modulus + floor(2^128/q) for the Barrett helpers, passed by value

@@ -153,6 +153,13 @@ int fhe_modmul_acc(fhe_ctx *ctx, uint64_t *d_c, const uint64_t *d_a, const uint6
 /* c = (a + b) mod q per limb (phantom::add_inplace, reliability_test/dotprod_test.cu:147) */
 int fhe_modadd(fhe_ctx *ctx, uint64_t *d_c, const uint64_t *d_a, const uint64_t *d_b, const fhe_ntt_tables *t, size_t n_poly,
                size_t limbs, size_t start_idx, void *stream);
+int fhe_modsub(fhe_ctx *ctx, uint64_t *d_c, const uint64_t *d_a, const uint64_t *d_b, const fhe_ntt_tables *t, size_t n_poly,
+               size_t limbs, size_t start_idx, void *stream);
+/* c = a * mul[l] + add[l] mod q_l with one host-side scalar pair per limb (either array may be NULL:
+ * mul defaults to 1, add to 0); limbs <= 64.  Scalar steps of mod-switching and BGV decryption
+ * (phantom::mod_switch_to_next_inplace / PhantomSecretKey::decrypt, dotprod_test.cu:115,119). */
+int fhe_scalar_affine(fhe_ctx *ctx, uint64_t *d_c, const uint64_t *d_a, const uint64_t *mul, const uint64_t *add,
+                      const fhe_ntt_tables *t, size_t n_poly, size_t limbs, size_t start_idx, void *stream);
 /* poly_mul_negacyclic_ntt (rfhe_framewk/src/negaclic_ntt.py:123-127): c = a * b mod (x^N + 1, q).
  * a and b are overwritten with their transforms (as the NTT-domain ciphertexts of the
  * reference stay transformed); c may alias a. */
@@ -203,6 +210,10 @@ int fhe_automorphism_ntt(fhe_ctx *ctx, uint64_t *d_dst, const uint64_t *d_src, i
  *   d_c   : L x N, NTT domain                       d_evk : dnum x 2 x (L+K) x N, NTT domain (b_d, a_d)
  *   d_out0, d_out1 : L x N, NTT domain; out0 + out1*s ~ c*s' when evk encrypts P*Qhat_d*[Qhat_d^-1]_{Q_d}*s'. */
 int fhe_keyswitch_create(fhe_ctx *ctx, const fhe_ntt_tables *t, int L, int K, int dnum, fhe_keyswitch **out);
+/* BGV form of the mod-down: with plaintext modulus `plain_modulus` (0 = off, the CKKS-style flooring
+ * above) the removed part delta satisfies delta = acc mod P and delta = 0 mod plain_modulus, so the
+ * plaintext is preserved exactly (scheme of reliability_test/dotprod_test.cu:199-204). */
+int fhe_keyswitch_set_plain_modulus(fhe_keyswitch *p, uint64_t plain_modulus);
 int fhe_keyswitch_destroy(fhe_keyswitch *p);
 int fhe_keyswitch_apply(fhe_ctx *ctx, fhe_keyswitch *p, uint64_t *d_out0, uint64_t *d_out1, const uint64_t *d_c,
                         const uint64_t *d_evk, void *stream);

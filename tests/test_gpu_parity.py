@@ -437,3 +437,34 @@ def test_ntt_real_test_cli_all_correct():
     assert r.returncode == 0 and r.stdout == "ALL CORRECT\n" and r.stderr == ""
     r = _run_cli("ntt_real_test", 16, 4, 1)
     assert r.stdout == "ALL CORRECT\n"
+
+
+# ----------------------------------------------- dotprod_test
+def test_dotprod_test_cli_matches_reference_log_format():
+    """BGV encrypted dot product over the engine (include/phantom_bgv_shim.hpp).  The line layout is the one
+    logged at reliability_test/data/bits1-16_num1.txt:4-37; without a fault the decrypted dot product equals
+    the CPU one (dotprod_test.cu:180-181), with a flipped ciphertext bit every slot is corrupted (:134-137)."""
+    import re
+    r = _run_cli("dotprod_test", 0, 0)
+    assert r.returncode == 0, r.stderr
+    head = ("/\n| Encryption parameters :\n|   scheme: BGV\n|   poly_modulus_degree: 16384\n"
+            "|   coeff_modulus size: 300 (50 + 50 + 50 + 50 + 50 + 50) bits\n\n"
+            "1125899903107073 ,  1125899903500289 ,  1125899903795201 ,  1125899903827969 ,  1125899903991809 ,  1125899904679937 ,  \n\n\\\n\n"
+            "Example: BGV HomMul test\nPlaintext matrix row size: 8192\nInput vector 1: \n    [ ")
+    assert r.stdout.startswith(head)
+    assert "Compute x * y homomorphically...\nRaw product vector: \n    [ " in r.stdout
+    assert "Elementwise symbol errors: 0 / 16384\nElementwise Hamming distance (bit errors): 0\n" in r.stdout
+    m = re.search(r"Decrypted dot product = (\d+)\nExpected \(CPU\)         = (\d+)\n"
+                  r"Dot product bit errors \(Hamming distance\): 0\nAbsolute difference   = 0\nPercentage error      = 0%\n"
+                  r"✔ Dot product matches CPU result.\n$", r.stdout)
+    assert m and m.group(1) == m.group(2)
+    # one flipped bit in the ciphertext (run_dotprod_simu.sh:17)
+    r = _run_cli("dotprod_test", 1, 1)
+    assert r.returncode == 0
+    assert re.search(r"^Injected bitflip @ idx=\d+, bit=\d+$", r.stderr, re.M)
+    m = re.search(r"Elementwise symbol errors: (\d+) / 16384\nElementwise Hamming distance \(bit errors\): (\d+)\n", r.stdout)
+    assert m
+    if int(m.group(1)) == 16384:          # a flip in a low-order noise bit can be absorbed; otherwise everything breaks
+        assert 120000 < int(m.group(2)) < 200000      # the reference logs ~158800 (bits1-16_num1.txt:30)
+        assert "✖ MISMATCH detected!" in r.stdout or "✔ Dot product matches CPU result." in r.stdout
+    assert _run_cli("dotprod_test", 1).returncode == 1       # usage error (dotprod_test.cu:190-194)
