@@ -191,12 +191,50 @@ def main():
             del buf
             return {"ntt_per_s": limbs * polys / (ms * 1e-3), "ms_per_step_device": ms,
                     "frac_of_hbm_roofline": 16.0 * N * limbs * polys / (ms * 1e-3) / 1e9 / HBM_PEAK_GBS}
+        def pointwise_rates():
+            # coefficient-wise products and base conversion at the configs[2] shape (N = 2^16, L = 16)
+            L2, P2 = 16, 16
+            q2 = F.create_moduli(N, [args.bits] * L2)
+            t2 = eng.tables(LOGN, q2)
+            mk = lambda: torch.randint(0, q2[0], (P2, L2, N), generator=g, device="cuda", dtype=torch.int64)
+            a, b, c = mk(), mk(), mk()
+            pa, pb, pc = (C.c_void_p(x.data_ptr()) for x in (a, b, c))
+            def timed(fn, steps=20):
+                for _ in range(3):
+                    fn()
+                torch.cuda.synchronize()
+                a0, a1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                a0.record(stream)
+                for _ in range(steps):
+                    fn()
+                a1.record(stream)
+                torch.cuda.synchronize()
+                return a0.elapsed_time(a1) / steps
+            units2 = L2 * P2
+            ms_mul = timed(lambda: check(lib.fhe_modmul(eng._h, pc, pa, pb, t2._h, P2, L2, 0, sptr)))
+            ms_poly = timed(lambda: check(lib.fhe_polymul(eng._h, pc, pa, pb, t2._h, P2, L2, 0, sptr)), steps=10)
+            out = {
+                "modmul_L16x16": {"ms_per_step_device": ms_mul, "GBps_algorithmic": 24.0 * N * units2 / (ms_mul * 1e-3) / 1e9,
+                                  "frac_of_hbm_roofline": 24.0 * N * units2 / (ms_mul * 1e-3) / 1e9 / HBM_PEAK_GBS},
+                "polymul_L16x16 (configs[2]: NTT, NTT, modmul, INTT)": {
+                    "ms_per_step_device": ms_poly, "limb_polymul_per_s": units2 / (ms_poly * 1e-3),
+                    "frac_of_hbm_roofline": 72.0 * N * units2 / (ms_poly * 1e-3) / 1e9 / HBM_PEAK_GBS},
+            }
+            m_in, k_out = 4, 4
+            bc = F.BaseConv(eng, q2[:m_in], q2[m_in:m_in + k_out])
+            src = torch.randint(0, q2[0], (m_in, 64 * N), generator=g, device="cuda", dtype=torch.int64)
+            dst = torch.empty((k_out, 64 * N), dtype=torch.int64, device="cuda")
+            ms_bc = timed(lambda: check(lib.fhe_baseconv_exact(eng._h, C.c_void_p(dst.data_ptr()), C.c_void_p(src.data_ptr()), bc._h, 64 * N, sptr)))
+            out["baseconv_exact_4to4_N=2^22"] = {"ms_per_step_device": ms_bc,
+                                                 "frac_of_hbm_roofline": 8.0 * 64 * N * (m_in + k_out) / (ms_bc * 1e-3) / 1e9 / HBM_PEAK_GBS}
+            return out
         result["also"] = {
             "inverse_same_batch": rate(args.limbs, args.polys, args.bits, inverse=True),
             "L16_distinct_primes_x16_polys (configs[2] shape)": rate(16, 16, args.bits),
             "hbm_streaming_1024_polys_512MiB (exceeds the 256 MiB Infinity Cache)": rate(1, 1024, args.bits, steps=5),
             "61bit_prime_integer_path": rate(1, args.polys, 61),
         }
+        result["also"].update(pointwise_rates())
 
     if rank == 0 and not args.no_cpu:
         from oracle import cport as O

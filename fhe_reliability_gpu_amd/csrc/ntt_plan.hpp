@@ -123,11 +123,15 @@ FHE_D u64 *row_tile_of(u32 unit, u32 tile, const PassArgs &a, u32 &limb, u32 &ro
     row0 = tile * RP::TROWS;
     return a.data + (((size_t)poly * a.poly_stride + l) << LOGN) + (size_t)row0 * RP::NPTS;
 }
+// Launch order of the two-launch path is limb-major (all polynomials of limb 0, then limb 1, ...): the
+// blocks in flight at any moment share one or two twiddle tables, which then live in the XCDs' L2
+// instead of being streamed from the Infinity Cache once per polynomial.
 template <class CP, int LOGN>
 FHE_D u64 *col_tile(u32 block, const PassArgs &a, u32 &limb)
 {
     const u32 unit = block / CP::TILES, tile = block % CP::TILES;
-    const u32 poly = unit / a.limbs, l = unit % a.limbs;
+    const u32 polys = a.units / a.limbs;
+    const u32 l = unit / polys, poly = unit % polys;
     limb = a.limb0 + l;
     return a.data + (((size_t)poly * a.poly_stride + l) << LOGN) + (size_t)tile * CP::TCOLS;
 }
@@ -135,7 +139,8 @@ template <class RP, int LOGN>
 FHE_D u64 *row_tile(u32 block, const PassArgs &a, u32 &limb, u32 &row0)
 {
     const u32 unit = block / RP::TILES, tile = block % RP::TILES;
-    const u32 poly = unit / a.limbs, l = unit % a.limbs;
+    const u32 polys = a.units / a.limbs;
+    const u32 l = unit / polys, poly = unit % polys;
     limb = a.limb0 + l;
     row0 = tile * RP::TROWS;
     return a.data + (((size_t)poly * a.poly_stride + l) << LOGN) + (size_t)row0 * RP::NPTS;
