@@ -3,7 +3,9 @@
 // same parameters (BGV, N = 16384, six 50-bit primes of which two special, 20-bit batching plain
 // modulus, :198-204) and the same printed lines (:57-58,70,81,90-91,110,134-139,164-184; logged
 // sample reliability_test/data/bits1-16_num1.txt:4-37), so run_dotprod_simu.sh keeps working.
-// Build with -DGEMM_LOOP for the naive_gemm_test.cu variant (100 encrypted dot products, keys reused).
+// Build with -DGEMM_LOOP for the naive_gemm_test.cu variant (100 encrypted dot products, keys reused),
+// with -DREAL_TEST for dotprod_real_test.cu: no arguments and no software flip (dotprod_real_test.cu:95-96,185),
+// so any mismatch is a hardware fault.
 #include <cstdlib>
 #include <ctime>
 #include <iostream>
@@ -16,6 +18,11 @@ using namespace phantom;
 using namespace phantom::arith;
 
 static EncryptionParameters parms(scheme_type::bgv);
+#ifdef REAL_TEST
+static const char *const PCT = " %";   // dotprod_real_test.cu:173
+#else
+static const char *const PCT = "%";    // dotprod_test.cu:176
+#endif
 
 // flip bits_per_symbol random bits in each of num_symbols random words of the ciphertext, on the device
 static void inject_bitflip_ciphertext(PhantomCiphertext &ct, int bits_per_symbol, int num_symbols)
@@ -63,7 +70,11 @@ static void dot_product_test(PhantomContext &context, int bits_per_symbol, int n
     public_key.encrypt_asymmetric(context, x_plain, x_cipher);
     public_key.encrypt_asymmetric(context, y_plain, y_cipher);
 
+#ifndef REAL_TEST
     inject_bitflip_ciphertext(x_cipher, bits_per_symbol, num_symbols);
+#else
+    (void)bits_per_symbol, (void)num_symbols, (void)inject_bitflip_ciphertext;
+#endif
 
     cout << "Compute x * y homomorphically..." << endl;
     PhantomCiphertext xy_cipher = multiply(context, x_cipher, y_cipher);
@@ -107,7 +118,7 @@ static void dot_product_test(PhantomContext &context, int bits_per_symbol, int n
     cout << "Dot product bit errors (Hamming distance): " << dp_bit_errors << endl;
     const uint64_t abs_diff = result_full > expected ? result_full - expected : expected - result_full;
     cout << "Absolute difference   = " << abs_diff << endl;
-    if (expected != 0) cout << "Percentage error      = " << (double)abs_diff / (double)expected * 100.0 << "%" << endl;
+    if (expected != 0) cout << "Percentage error      = " << (double)abs_diff / (double)expected * 100.0 << PCT << endl;
     else cout << "Percentage error      = undefined (expected is zero)" << endl;
     if (result_full == expected) cout << "✔ Dot product matches CPU result." << endl;
     else cout << "✖ MISMATCH detected!" << endl;
@@ -142,12 +153,16 @@ static vector<uint64_t> encrypted_dot_product(PhantomContext &context, PhantomSe
 int main(int argc, char *argv[])
 {
     srand((unsigned)time(NULL));
-#ifndef GEMM_LOOP
+#if !defined(GEMM_LOOP) && !defined(REAL_TEST)
     if (argc != 3) {
         cerr << "Usage: " << argv[0] << " <bits_per_symbol> <num_symbols>\n";
         return 1;
     }
     const int bits_per_symbol = atoi(argv[1]), num_symbols = atoi(argv[2]);
+#elif defined(REAL_TEST)
+    (void)argc;
+    (void)argv;
+    const int bits_per_symbol = 0, num_symbols = 0;
 #else
     (void)argc;
     (void)argv;

@@ -468,3 +468,20 @@ def test_dotprod_test_cli_matches_reference_log_format():
         assert 120000 < int(m.group(2)) < 200000      # the reference logs ~158800 (bits1-16_num1.txt:30)
         assert "✖ MISMATCH detected!" in r.stdout or "✔ Dot product matches CPU result." in r.stdout
     assert _run_cli("dotprod_test", 1).returncode == 1       # usage error (dotprod_test.cu:190-194)
+
+
+def test_dotprod_real_test_cli():
+    """dotprod_real_test.cu: no arguments, no software flip -> the encrypted dot product matches the CPU one."""
+    r = _run_cli("dotprod_real_test")
+    assert r.returncode == 0, r.stderr
+    assert "Injected bitflip" not in r.stderr
+    assert "Elementwise symbol errors: 0 / 16384\n" in r.stdout
+    assert "Percentage error      = 0 %\n" in r.stdout
+    assert r.stdout.endswith("✔ Dot product matches CPU result.\n")
+
+
+def test_naive_gemm_test_cli():
+    """naive_gemm_test.cu:94-100: 100 encrypted dot products with the keys reused; silent timing body."""
+    r = _run_cli("naive_gemm_test")
+    assert r.returncode == 0, r.stderr
+    assert "MISMATCH" not in r.stdout
