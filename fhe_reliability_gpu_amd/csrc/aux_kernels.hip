@@ -245,54 +245,108 @@ hipError_t launch_transpose(hipStream_t st, u64 *out, const u64 *in, u32 rows, u
 // ---------------------------------------------------------------------------
 constexpr int BC_MAX_LIMBS = 64;
 
-// digits of x in the mixed radix (p_0, p_1, ...): x = c_0 + c_1 p_0 + c_2 p_0 p_1 + ...
-template <int MAXM>
-__device__ __forceinline__ void garner_digits(u64 (&c)[MAXM], const u64 *in, u64 N, u64 i, const BaseConvPlanDev &pl)
+// Exact conversion (motivation/baseConv.py:67-83): mixed-radix digits of x over (p_0, p_1, ...),
+// x = c_0 + c_1 p_0 + c_2 p_0 p_1 + ..., then x mod q_o.  The reference's nested recurrence
+// t = (t - c_l) p_l^-1 is unrolled into independent constant products
+//   c_j = r_j A_j - sum_{l<j} c_l D_lj (mod p_j),   x mod q_o = sum_l c_l E_lo (mod q_o)
+// (constants in BaseConvPlanDev), every product one lazy multiply of the limb's arithmetic path: no
+// dependent multiply chain and no 128-bit Barrett step.  Same canonical digits, same outputs.
+struct BcF64 {
+    typedef double acc_t;
+    static __device__ __forceinline__ double load(u64 raw, u64 q) { return ArithF64::from_canonical(raw < q ? raw : reduce_any_u64(raw, q)); }
+    static __device__ __forceinline__ ArithF64::Ctx ctx(u64 q, const Tw &fp) { return ArithF64::Ctx{u64_bits_to_double(fp.a), u64_bits_to_double(fp.b), q}; }
+    static __device__ __forceinline__ double mul(double a, const Tw &t, const ArithF64::Ctx &c) { return ArithF64::mulmod(a, t, c); }
+    static __device__ __forceinline__ double sub(double a, double b, const ArithF64::Ctx &) { return a - b; }
+    static __device__ __forceinline__ double add(double a, double b, const ArithF64::Ctx &) { return a + b; }
+    // |product| < 0.75 q: eight of them stay below 2^53
+    static __device__ __forceinline__ void relax(double &a, int terms, const ArithF64::Ctx &c)
+    {
+        if ((terms & 7) == 7) ArithF64::reduce(a, c);
+    }
+    static __device__ __forceinline__ double digit(double a, const ArithF64::Ctx &c)
+    {
+        ArithF64::reduce(a, c);
+        return a < 0.0 ? a + c.n : a;
+    }
+    static __device__ __forceinline__ u64 out(double a, const ArithF64::Ctx &c) { return ArithF64::canonical(a, c); }
+};
+struct BcU64 {
+    typedef u64 acc_t;
+    struct Ctx {
+        u64 q;
+    };
+    static __device__ __forceinline__ u64 load(u64 raw, u64) { return raw; }   // the Shoup product takes any 64-bit word
+    static __device__ __forceinline__ Ctx ctx(u64 q, const Tw &) { return Ctx{q}; }
+    static __device__ __forceinline__ u64 mul(u64 a, const Tw &t, const Ctx &c) { return mulmod_shoup(a, t.a, t.b, c.q); }
+    static __device__ __forceinline__ u64 sub(u64 a, u64 b, const Ctx &c) { return a >= b ? a - b : a + c.q - b; }
+    static __device__ __forceinline__ u64 add(u64 a, u64 b, const Ctx &c)
+    {
+        const u64 s = a + b;
+        return s >= c.q ? s - c.q : s;
+    }
+    static __device__ __forceinline__ void relax(u64 &, int, const Ctx &) {}
+    static __device__ __forceinline__ u64 digit(u64 a, const Ctx &) { return a; }
+    static __device__ __forceinline__ u64 out(u64 a, const Ctx &) { return a; }
+};
+
+template <int MAXM, class B>
+__global__ __launch_bounds__(256) void k_baseconv_exact(u64 *__restrict__ out, const u64 *__restrict__ in, BaseConvPlanDev pl, u64 N)
 {
-    const int m = pl.m;
-    for (int j = 0; j < m && j < MAXM; j++) {
-        const u64 pj = pl.mod_in[j], r0 = pl.ratio_in[2 * j], r1 = pl.ratio_in[2 * j + 1];
-        u64 t = barrett128(in[(u64)j * N + i], 0, pj, r0, r1);
-        // t = (...((r_j - c_0) p_0^-1 - c_1) p_1^-1 ...) mod p_j
-        for (int l = 0; l < j; l++) {
-            const u64 cl = barrett128(c[l], 0, pj, r0, r1);
-            const u64 d = t >= cl ? t - cl : t + pj - cl;
-            t = mulmod_b(d, pl.inv_pl_mod_pj[l * m + j], pj, r0, r1);
+    typedef typename B::acc_t T;
+    constexpr int UNR = MAXM <= 8 ? MAXM : 1;   // small bases: digits in registers; larger ones index a scratch array
+    const int m = pl.m, k = pl.k;
+    const Tw FHE_GLOBAL *dig = (const Tw FHE_GLOBAL *)pl.dig, *hor = (const Tw FHE_GLOBAL *)pl.hor;
+    const Tw FHE_GLOBAL *fp_in = (const Tw FHE_GLOBAL *)pl.fp_in, *fp_out = (const Tw FHE_GLOBAL *)pl.fp_out;
+    const u64 FHE_GLOBAL *mod_in = (const u64 FHE_GLOBAL *)pl.mod_in, *mod_out = (const u64 FHE_GLOBAL *)pl.mod_out;
+    for (u64 i = blockIdx.x * (u64)blockDim.x + threadIdx.x; i < N; i += (u64)gridDim.x * blockDim.x) {
+        T c[MAXM];
+#pragma unroll UNR
+        for (int j = 0; j < MAXM; j++) {
+            if (j < m) {
+                const u64 pj = mod_in[j];
+                const auto cx = B::ctx(pj, fp_in[j]);
+                T t = B::mul(B::load(in[(u64)j * N + i], pj), dig[j * m + j], cx);
+#pragma unroll UNR
+                for (int l = 0; l < j; l++) {
+                    t = B::sub(t, B::mul(c[l], dig[l * m + j], cx), cx);
+                    B::relax(t, l + 1, cx);
+                }
+                c[j] = B::digit(t, cx);
+            }
         }
-        c[j] = t;
+        for (int o = 0; o < k; o++) {
+            const u64 q = mod_out[o];
+            const auto cx = B::ctx(q, fp_out[o]);
+            T acc = B::mul(c[0], hor[o], cx);
+#pragma unroll UNR
+            for (int l = 1; l < MAXM; l++) {
+                if (l < m) {
+                    acc = B::add(acc, B::mul(c[l], hor[l * k + o], cx), cx);
+                    B::relax(acc, l, cx);
+                }
+            }
+            out[(u64)o * N + i] = B::out(acc, cx);
+        }
     }
 }
 
-template <int MAXM>
-__global__ __launch_bounds__(256) void k_baseconv_exact(u64 *out, const u64 *in, BaseConvPlanDev pl, u64 N)
+template <class B>
+static void launch_exact(hipStream_t st, dim3 grid, u64 *out, const u64 *in, const BaseConvPlanDev &pl, u64 N)
 {
-    for (u64 i = blockIdx.x * (u64)blockDim.x + threadIdx.x; i < N; i += (u64)gridDim.x * blockDim.x) {
-        u64 c[MAXM];
-        garner_digits<MAXM>(c, in, N, i, pl);
-        // motivation/baseConv.py:79-81: x mod q_o, Horner over the mixed-radix digits
-        for (int o = 0; o < pl.k; o++) {
-            const u64 q = pl.mod_out[o], r0 = pl.ratio_out[2 * o], r1 = pl.ratio_out[2 * o + 1];
-            u64 acc = 0;
-            for (int l = pl.m - 1; l >= 0; l--) {
-                acc = mulmod_b(acc, pl.pl_mod_qo[l * pl.k + o], q, r0, r1);
-                const u64 cl = barrett128(c[l], 0, q, r0, r1);
-                acc += cl;
-                acc = acc >= q ? acc - q : acc;
-            }
-            out[(u64)o * N + i] = acc;
-        }
-    }
+    if (pl.m <= 4) hipLaunchKernelGGL((k_baseconv_exact<4, B>), grid, dim3(256), 0, st, out, in, pl, N);
+    else if (pl.m <= 8) hipLaunchKernelGGL((k_baseconv_exact<8, B>), grid, dim3(256), 0, st, out, in, pl, N);
+    else if (pl.m <= 16) hipLaunchKernelGGL((k_baseconv_exact<16, B>), grid, dim3(256), 0, st, out, in, pl, N);
+    else if (pl.m <= 32) hipLaunchKernelGGL((k_baseconv_exact<32, B>), grid, dim3(256), 0, st, out, in, pl, N);
+    else hipLaunchKernelGGL((k_baseconv_exact<64, B>), grid, dim3(256), 0, st, out, in, pl, N);
 }
 
 hipError_t launch_baseconv_exact(hipStream_t st, u64 *out, const u64 *in, const BaseConvPlanDev &pl, u64 N)
 {
     if (pl.m > BC_MAX_LIMBS) return hipErrorInvalidValue;
     u64 want = (N + 255) / 256;
-    const dim3 grid((u32)(want > 4096 ? 4096 : want));
-    if (pl.m <= 8) hipLaunchKernelGGL(k_baseconv_exact<8>, grid, dim3(256), 0, st, out, in, pl, N);
-    else if (pl.m <= 16) hipLaunchKernelGGL(k_baseconv_exact<16>, grid, dim3(256), 0, st, out, in, pl, N);
-    else if (pl.m <= 32) hipLaunchKernelGGL(k_baseconv_exact<32>, grid, dim3(256), 0, st, out, in, pl, N);
-    else hipLaunchKernelGGL(k_baseconv_exact<64>, grid, dim3(256), 0, st, out, in, pl, N);
+    const dim3 grid((u32)(want > 16384 ? 16384 : want));
+    if (pl.f64) launch_exact<BcF64>(st, grid, out, in, pl, N);
+    else launch_exact<BcU64>(st, grid, out, in, pl, N);
     return hipGetLastError();
 }
 

@@ -82,7 +82,7 @@ struct fhe_ntt_tables {
 struct fhe_baseconv {
     int m = 0, k = 0;
     bool fast_ok = true;
-    DevBuf mod_in, mod_out, ratio_in, ratio_out, inv_pl_pj, pl_qo, fast_coef, fast_shoup;
+    DevBuf mod_in, mod_out, dig, hor, fp_in, fp_out, fast_coef, fast_shoup;
     BaseConvPlanDev dev{};
 };
 
@@ -1083,32 +1083,43 @@ int fhe_baseconv_create(fhe_ctx *ctx, const uint64_t *mod_in, int m, const uint6
     std::unique_ptr<fhe_baseconv> p(new fhe_baseconv);
     p->m = m;
     p->k = k;
-    std::vector<u64> mi(mod_in, mod_in + m), mo(mod_out, mod_out + k), ri(2 * m), ro(2 * k), ipp((size_t)m * m, 0), pq((size_t)m * k),
-        fc((size_t)m * k), fs((size_t)m * k);
-    u64 maxq = 0;
+    std::vector<u64> mi(mod_in, mod_in + m), mo(mod_out, mod_out + k), fc((size_t)m * k), fs((size_t)m * k);
+    u64 maxq = 0, maxall = 0;
     for (int j = 0; j < m; j++) {
         if (mi[j] < 2 || mi[j] >= ((u64)1 << 62)) return fail(FHE_ERR_UNSUPPORTED, "input modulus out of range");
-        u64 cr[3];
-        host::const_ratio(mi[j], cr);
-        ri[2 * j] = cr[0];
-        ri[2 * j + 1] = cr[1];
+        maxall = std::max(maxall, mi[j]);
     }
     for (int o = 0; o < k; o++) {
         if (mo[o] < 2 || mo[o] >= ((u64)1 << 62)) return fail(FHE_ERR_UNSUPPORTED, "output modulus out of range");
-        u64 cr[3];
-        host::const_ratio(mo[o], cr);
-        ro[2 * o] = cr[0];
-        ro[2 * o + 1] = cr[1];
-        maxq = mo[o] > maxq ? mo[o] : maxq;
+        maxq = std::max(maxq, mo[o]);
     }
-    for (int l = 0; l < m; l++)
-        for (int j = l + 1; j < m; j++) {
-            const u64 inv = host::inv_mod(mi[l] % mi[j], mi[j]);
-            if (!inv && mi[j] != 1) return fail(FHE_ERR_INVALID, "input moduli must be pairwise coprime");
-            ipp[(size_t)l * m + j] = inv;
+    maxall = std::max(maxall, maxq);
+    // constants of the exact conversion (aux_kernels.hip k_baseconv_exact), encoded for the arithmetic path
+    const bool f64 = maxall < ((u64)1 << 50);
+    auto enc = [&](u64 w, u64 q) { return f64 ? ArithF64::encode(w, q) : ArithU64::encode(w, q); };
+    auto fp = [](u64 q) { return Tw{double_to_u64_bits((double)q), double_to_u64_bits(1.0 / (double)q)}; };
+    std::vector<Tw> dig((size_t)m * m, Tw{0, 0}), hor((size_t)m * k), fpi(m), fpo(k);
+    for (int j = 0; j < m; j++) {
+        fpi[j] = fp(mi[j]);
+        // D_lj = (p_l ... p_{j-1})^-1 mod p_j for l = j-1 .. 0; A_j = D_0j (1 for j = 0)
+        u64 prod = 1 % mi[j];
+        for (int l = j - 1; l >= 0; l--) {
+            prod = host::mul_mod(prod, mi[l] % mi[j], mi[j]);
+            const u64 inv = host::inv_mod(prod, mi[j]);
+            if (!inv) return fail(FHE_ERR_INVALID, "input moduli must be pairwise coprime");
+            dig[(size_t)l * m + j] = enc(inv, mi[j]);
+            if (l == 0) dig[(size_t)j * m + j] = enc(inv, mi[j]);
         }
-    for (int l = 0; l < m; l++)
-        for (int o = 0; o < k; o++) pq[(size_t)l * k + o] = mi[l] % mo[o];
+        if (j == 0) dig[0] = enc(1 % mi[0], mi[0]);
+    }
+    for (int o = 0; o < k; o++) {
+        fpo[o] = fp(mo[o]);
+        u64 prod = 1 % mo[o];
+        for (int l = 0; l < m; l++) {
+            hor[(size_t)l * k + o] = enc(prod, mo[o]);
+            prod = host::mul_mod(prod, mi[l] % mo[o], mo[o]);
+        }
+    }
     // rfhe_framewk/src/baseConv.py:17-18: hat_p[j] = P // p_j, inv_hat_p[j] = hat_p[j]^-1 mod p_j
     for (int j = 0; j < m; j++) {
         u64 hat_pj = 1 % mi[j];
@@ -1128,14 +1139,14 @@ int fhe_baseconv_create(fhe_ctx *ctx, const uint64_t *mod_in, int m, const uint6
     HIP_TRY(hipSetDevice(ctx->device));
     HIP_TRY(p->mod_in.upload(mi));
     HIP_TRY(p->mod_out.upload(mo));
-    HIP_TRY(p->ratio_in.upload(ri));
-    HIP_TRY(p->ratio_out.upload(ro));
-    HIP_TRY(p->inv_pl_pj.upload(ipp));
-    HIP_TRY(p->pl_qo.upload(pq));
+    HIP_TRY(p->dig.upload(dig));
+    HIP_TRY(p->hor.upload(hor));
+    HIP_TRY(p->fp_in.upload(fpi));
+    HIP_TRY(p->fp_out.upload(fpo));
     HIP_TRY(p->fast_coef.upload(fc));
     HIP_TRY(p->fast_shoup.upload(fs));
-    p->dev = BaseConvPlanDev{m, k, p->mod_in.as<u64>(), p->mod_out.as<u64>(), p->ratio_in.as<u64>(), p->ratio_out.as<u64>(),
-                             p->inv_pl_pj.as<u64>(), p->pl_qo.as<u64>(), p->fast_coef.as<u64>(), p->fast_shoup.as<u64>()};
+    p->dev = BaseConvPlanDev{m, k, p->mod_in.as<u64>(), p->mod_out.as<u64>(), p->dig.as<Tw>(), p->hor.as<Tw>(), p->fp_in.as<Tw>(),
+                             p->fp_out.as<Tw>(), f64 ? 1 : 0, p->fast_coef.as<u64>(), p->fast_shoup.as<u64>()};
     *out = p.release();
     return FHE_OK;
 }

@@ -69,10 +69,11 @@ struct BaseConvPlanDev {
     int m, k;
     const u64 *mod_in;        // m
     const u64 *mod_out;       // k
-    const u64 *ratio_in;      // m x 2   floor(2^128/p_j)
-    const u64 *ratio_out;     // k x 2
-    const u64 *inv_pl_mod_pj; // m x m   (p_l)^-1 mod p_j  (l < j)
-    const u64 *pl_mod_qo;     // m x k   p_l mod q_o
+    // exact conversion, mixed-radix digits c_j = r_j*A_j - sum_{l<j} c_l*D_lj (mod p_j) and x = sum_l c_l*E_lo (mod q_o):
+    const Tw *dig;            // m x m   [j*m+j] = A_j = (p_0..p_{j-1})^-1 mod p_j;  [l*m+j], l<j = D_lj = (p_l..p_{j-1})^-1 mod p_j
+    const Tw *hor;            // m x k   E_lo = p_0..p_{l-1} mod q_o
+    const Tw *fp_in, *fp_out; // m, k    {bits((double)q), bits(1.0/q)} per modulus (ArithF64 context)
+    int f64;                  // 1: every modulus < 2^50, constants encoded for ArithF64; 0: Shoup pairs (ArithU64)
     const u64 *fast_coef;     // m x k   (Phat_j * inv_j) mod q_o   (rfhe_framewk/src/baseConv.py:17-29)
     const u64 *fast_coef_shoup;
 };
