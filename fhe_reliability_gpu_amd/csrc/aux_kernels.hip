@@ -6,25 +6,6 @@
 
 namespace fhe {
 
-// (hi:lo) mod q with ratio = floor(2^128/q) = (r1:r0).  Exact quotient estimate:
-// floor(x*ratio/2^128) is floor(x/q) or one less, so one subtraction finishes; a
-// second is kept for robustness.  This is the 128->64 Barrett step Phantom's
-// DModulus carries its const_ratio for (reliability_test/ntt_test.cu:49-53).
-__device__ __forceinline__ u64 barrett128(u64 lo, u64 hi, u64 q, u64 r0, u64 r1)
-{
-    const u64 c = __umul64hi(lo, r0);
-    const u64 t1l = lo * r1, t1h = __umul64hi(lo, r1);
-    const u64 t2l = hi * r0, t2h = __umul64hi(hi, r0);
-    u64 s = t1l + t2l;
-    u64 carry = s < t1l;
-    const u64 s2 = s + c;
-    carry += s2 < s;
-    const u64 qhat = hi * r1 + t1h + t2h + carry;
-    u64 r = lo - qhat * q;
-    r = r >= q ? r - q : r;
-    r = r >= q ? r - q : r;
-    return r;
-}
 __device__ __forceinline__ u64 mulmod_b(u64 a, u64 b, u64 q, u64 r0, u64 r1)
 {
     return barrett128(a * b, __umul64hi(a, b), q, r0, r1);

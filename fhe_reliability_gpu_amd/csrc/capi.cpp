@@ -789,6 +789,23 @@ int fhe_polymul(fhe_ctx *ctx, uint64_t *c, uint64_t *a, uint64_t *b, const fhe_n
                 size_t start_idx, void *stream)
 {
     int rc;
+    if (!ctx || !c || !a || !b) return fail(FHE_ERR_INVALID, "null argument");
+    if ((rc = check_range(t, n_poly, limbs, start_idx))) return rc;
+    if (!t->has_inverse) return fail(FHE_ERR_UNSUPPORTED, "table set has no inverse (twiddle or N not invertible)");
+    if (!n_poly || !limbs) return FHE_OK;
+    if (ctx->mode == 0 && ctx->fault_idx < 0 && polymul_fused_supported(t->log_n)) {
+        HIP_TRY(hipSetDevice(ctx->device));
+        hipStream_t st = pick(ctx, stream);
+        const size_t N = (size_t)1 << t->log_n;
+        TraceScope tr(ctx, st, "POLYMUL");
+        return for_each_run(t, limbs, start_idx, [&](size_t off, size_t len, int path) -> int {
+            PassArgs pa{a + off * N, t->d_lp.as<LimbParams>(), (u32)(start_idx + off), (u32)len, (u32)(n_poly * len), (u32)limbs};
+            hipError_t e = launch_polymul(st, pa, b + off * N, c + off * N, t->log_n, path);
+            if (e != hipSuccess) return hip_fail(e, "launch_polymul");
+            return FHE_OK;
+        });
+    }
+    // unfused sequence (tiny sizes, fused-NTT mode, fault-injection hook)
     if ((rc = ntt_batch(ctx, a, t, n_poly, limbs, start_idx, stream, false))) return rc;
     if (b != a && (rc = ntt_batch(ctx, b, t, n_poly, limbs, start_idx, stream, false))) return rc;
     if ((rc = pointwise(ctx, c, a, b, t, n_poly, limbs, start_idx, stream, false))) return rc;

@@ -124,6 +124,26 @@ __host__ __device__ __attribute__((noinline)) inline u64 reduce_any_u64(u64 x, u
 inline u64 reduce_any_u64(u64 x, u64 q) { return x % q; }
 #endif
 
+// (hi:lo) mod q with ratio = floor(2^128/q) = (r1:r0).  Exact quotient estimate:
+// floor(x*ratio/2^128) is floor(x/q) or one less, so one subtraction finishes; a
+// second is kept for robustness.  This is the 128->64 Barrett step Phantom's
+// DModulus carries its const_ratio for (reliability_test/ntt_test.cu:49-53).
+FHE_HD u64 barrett128(u64 lo, u64 hi, u64 q, u64 r0, u64 r1)
+{
+    const u64 c = mulhi64(lo, r0);
+    const u64 t1l = lo * r1, t1h = mulhi64(lo, r1);
+    const u64 t2l = hi * r0, t2h = mulhi64(hi, r0);
+    u64 s = t1l + t2l;
+    u64 carry = s < t1l;
+    const u64 s2 = s + c;
+    carry += s2 < s;
+    const u64 qhat = hi * r1 + t1h + t2h + carry;
+    u64 r = lo - qhat * q;
+    r = r >= q ? r - q : r;
+    r = r >= q ? r - q : r;
+    return r;
+}
+
 // ---------------------------------------------------------------------------
 // ArithF64
 // ---------------------------------------------------------------------------
@@ -188,6 +208,18 @@ struct ArithF64 {
         Y = mulmod(d, t, c);
     }
     static FHE_HD elem add(elem a, elem b) { return a + b; }
+    // product of two canonical residues, canonical result.  The quotient estimate rint(x * (y/q)) is off by
+    // less than 0.5 + 0.375 (three roundings on a value below 2^50), so h - k*q + l is an exact integer
+    // in (-0.875 q, 0.875 q).
+    static FHE_HD u64 mulvar(u64 x, u64 y, const LimbParams &p)
+    {
+        const Ctx c = make_ctx(p);
+        const double a = from_canonical(x), b = from_canonical(y);
+        const double h = a * b;
+        const double k = __builtin_rint(a * (b * c.ninv));
+        const double l = __builtin_fma(a, b, -h);
+        return canonical(__builtin_fma(-k, c.n, h) + l, c);
+    }
     // host: encode a residue w (< q) as a twiddle
     static inline Tw encode(u64 w, u64 q)
     {
@@ -241,6 +273,7 @@ struct ArithU64 {
         X = s >= c.two_q ? s - c.two_q : s;
         Y = mulmod(d, t, c);
     }
+    static FHE_HD u64 mulvar(u64 x, u64 y, const LimbParams &p) { return barrett128(x * y, mulhi64(x, y), p.q, p.barrett_lo, p.barrett_hi); }
     static inline Tw encode(u64 w, u64 q) { return Tw{w, (u64)(((unsigned __int128)w << 64) / q)}; }
 };
 

@@ -6,6 +6,8 @@
 #include "ntt_launch.hpp"
 #include "ntt_plan.hpp"
 
+#include <type_traits>
+
 namespace fhe {
 
 template <class PASS, int LOGN, bool INV, bool IS_COL>
@@ -81,6 +83,132 @@ static hipError_t launch_size(hipStream_t st, const PassArgs &a, int logn, bool 
     default:
         return hipErrorInvalidValue;
     }
+}
+
+// ---------------------------------------------------------------------------
+// Negacyclic product, middle launch: for one row tile, finish the forward transform of a and of b
+// (row pass), multiply, and run the first inverse pass (the row pass again), reading each input tile
+// once and writing the product tile once.  The forward row pass leaves final words in the LDS image
+// where its copy-out phase would read them, and the inverse row pass expects raw words where its
+// copy-in phase would put them: same image, so a's tile goes to registers (one pair per lane and
+// 2*NTT_THREADS words), b's tile is multiplied in place in LDS, and the inverse steps carry on.
+// For single-pass sizes this is the whole product in one launch.
+// ---------------------------------------------------------------------------
+struct PolymulArgs {
+    PassArgs a;     // a.data = first factor (tile mapping as for a row pass)
+    const u64 *b;   // second factor, same layout
+    u64 *c;         // product (may alias either factor)
+};
+
+template <class FR, int E = 0>
+FHE_D void fwd_steps(int tid, u64 *base, typename FR::elem *lds, TwPtr tw, u32 row0, const typename FR::Arith::Ctx &ctx, const Tw &inv_n)
+{
+    if constexpr (E < FR::NSTEP) {
+        if (E > 0) __syncthreads();
+        FR::template phase<E>(tid, base, lds, tw, row0, ctx, inv_n);
+        fwd_steps<FR, E + 1>(tid, base, lds, tw, row0, ctx, inv_n);
+    }
+}
+template <class IR, int E = 1>
+FHE_D void inv_steps(int tid, u64 *base, typename IR::elem *lds, TwPtr tw, u32 row0, const typename IR::Arith::Ctx &ctx, const Tw &inv_n)
+{
+    if constexpr (E < IR::NPHASE) {
+        __syncthreads();
+        IR::template phase<E>(tid, base, lds, tw, row0, ctx, inv_n);
+        inv_steps<IR, E + 1>(tid, base, lds, tw, row0, ctx, inv_n);
+    }
+}
+
+template <class A, int LOGN, int GEO>
+__global__ __launch_bounds__(NTT_THREADS) void k_polymul_mid(PolymulArgs pa)
+{
+    typedef Passes<A, LOGN, false, GEO> F;
+    typedef Passes<A, LOGN, true, GEO> I;
+    typedef typename std::conditional<F::G::TWO_PASS, typename F::Row, typename F::Single>::type FR;
+    typedef typename std::conditional<F::G::TWO_PASS, typename I::Row, typename I::Single>::type IR;
+    static_assert(FR::STAGED && IR::STAGED && FR::LDS_ELEMS == IR::LDS_ELEMS, "fused product needs the staged row pass");
+    typedef typename FR::elem elem;
+    constexpr int PAIRS = FR::TROWS * FR::NPTS / 2;
+    constexpr int PER = (PAIRS + NTT_THREADS - 1) / NTT_THREADS;
+    __shared__ __attribute__((aligned(16))) elem lds[FR::LDS_ELEMS];
+    u32 limb, row0;
+    u64 *ta = row_tile<FR, LOGN>(blockIdx.x, pa.a, limb, row0);
+    const size_t off = (size_t)(ta - pa.a.data);
+    const LimbParams &p = pa.a.lp[limb];
+    const typename A::Ctx ctx = A::make_ctx(p);
+    const Tw inv_n = p.inv_n;
+    const int tid = threadIdx.x;
+
+    fwd_steps<FR>(tid, ta, lds, as_global(p.fwd), row0, ctx, inv_n);
+    __syncthreads();
+    u64 ra[PER][2];
+#pragma unroll
+    for (int k = 0; k < PER; k++) {
+        const int i = tid + k * NTT_THREADS;
+        if (PAIRS % NTT_THREADS == 0 || i < PAIRS) {
+            const u32 row = (u32)i / (FR::NPTS / 2), g = ((u32)i % (FR::NPTS / 2)) * 2;
+            const elem *src = lds + row * FR::ROW_LDS + row_pad(g);
+            ra[k][0] = __builtin_bit_cast(u64, src[0]);
+            ra[k][1] = __builtin_bit_cast(u64, src[1]);
+        }
+    }
+    __syncthreads();
+    fwd_steps<FR>(tid, const_cast<u64 *>(pa.b) + off, lds, as_global(p.fwd), row0, ctx, inv_n);
+    __syncthreads();
+#pragma unroll
+    for (int k = 0; k < PER; k++) {
+        const int i = tid + k * NTT_THREADS;
+        if (PAIRS % NTT_THREADS == 0 || i < PAIRS) {
+            const u32 row = (u32)i / (FR::NPTS / 2), g = ((u32)i % (FR::NPTS / 2)) * 2;
+            elem *dst = lds + row * FR::ROW_LDS + row_pad(g);
+            dst[0] = __builtin_bit_cast(elem, A::mulvar(ra[k][0], __builtin_bit_cast(u64, dst[0]), p));
+            dst[1] = __builtin_bit_cast(elem, A::mulvar(ra[k][1], __builtin_bit_cast(u64, dst[1]), p));
+        }
+    }
+    inv_steps<IR>(tid, pa.c + off, lds, as_global(p.inv), row0, ctx, inv_n);
+}
+
+template <class A, int LOGN>
+static hipError_t launch_mid(hipStream_t st, const PolymulArgs &pa)
+{
+    constexpr int GEO = LOGN >= 13 ? 1 : 0;
+    typedef Passes<A, LOGN, false, GEO> F;
+    typedef typename std::conditional<F::G::TWO_PASS, typename F::Row, typename F::Single>::type FR;
+    hipLaunchKernelGGL((k_polymul_mid<A, LOGN, GEO>), dim3(pa.a.units * FR::TILES), dim3(NTT_THREADS), 0, st, pa);
+    return hipGetLastError();
+}
+
+bool polymul_fused_supported(int logn) { return logn >= 5 && logn <= NTT_MAX_LOGN; }
+
+// c = a * b in Z_q[x]/(x^N + 1) for a.units limb-polynomials: forward column passes (two-pass sizes), the
+// middle launch above, inverse column pass.  a and b are scratch afterwards; c may alias either.
+hipError_t launch_polymul(hipStream_t st, const PassArgs &a, u64 *b, u64 *c, int logn, int path)
+{
+    if (a.units == 0) return hipSuccess;
+    if (!polymul_fused_supported(logn)) return hipErrorInvalidValue;
+    hipError_t e;
+    PassArgs pb = a, pc = a;
+    pb.data = b;
+    pc.data = c;
+    if (logn >= 13) {
+        if ((e = launch_ntt(st, a, logn, false, path, 1, 0)) != hipSuccess) return e;
+        if (b != a.data && (e = launch_ntt(st, pb, logn, false, path, 1, 0)) != hipSuccess) return e;
+    }
+    const PolymulArgs pa{a, b, c};
+    switch (logn) {
+#define FHE_CASE(L)                                                                                     \
+    case L:                                                                                             \
+        e = path == PATH_F64 ? launch_mid<ArithF64, L>(st, pa) : launch_mid<ArithU64, L>(st, pa);       \
+        break;
+        FHE_CASE(5) FHE_CASE(6) FHE_CASE(7) FHE_CASE(8) FHE_CASE(9) FHE_CASE(10) FHE_CASE(11) FHE_CASE(12) FHE_CASE(13)
+        FHE_CASE(14) FHE_CASE(15) FHE_CASE(16) FHE_CASE(17) FHE_CASE(18) FHE_CASE(19) FHE_CASE(20)
+#undef FHE_CASE
+    default:
+        return hipErrorInvalidValue;
+    }
+    if (e != hipSuccess) return e;
+    if (logn >= 13) return launch_ntt(st, pc, logn, true, path, 1, 1);
+    return hipSuccess;
 }
 
 // (Chunking large batches so that the second launch would find the first launch's output in the

@@ -11,6 +11,11 @@ namespace fhe {
 // which: -1 whole transform; 0 / 1 = only the first / second launch of a two-pass size
 hipError_t launch_ntt(hipStream_t st, const PassArgs &a, int logn, bool inverse, int path, int geo = 1, int which = -1);
 
+// c = a * b mod (x^N + 1, q_l): forward column passes, one launch that finishes both forward transforms,
+// multiplies and starts the inverse, inverse column pass.  a and b are scratch afterwards.
+bool polymul_fused_supported(int logn);
+hipError_t launch_polymul(hipStream_t st, const PassArgs &a, u64 *b, u64 *c, int logn, int path);
+
 // ---- ntt_fused.hip: single-launch variant for two-pass sizes --------------------
 bool fused_supported(int logn);
 size_t fused_ctl_bytes(u32 units);

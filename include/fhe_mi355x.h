@@ -161,8 +161,8 @@ int fhe_modsub(fhe_ctx *ctx, uint64_t *d_c, const uint64_t *d_a, const uint64_t 
 int fhe_scalar_affine(fhe_ctx *ctx, uint64_t *d_c, const uint64_t *d_a, const uint64_t *mul, const uint64_t *add,
                       const fhe_ntt_tables *t, size_t n_poly, size_t limbs, size_t start_idx, void *stream);
 /* poly_mul_negacyclic_ntt (rfhe_framewk/src/negaclic_ntt.py:123-127): c = a * b mod (x^N + 1, q).
- * a and b are overwritten with their transforms (as the NTT-domain ciphertexts of the
- * reference stay transformed); c may alias a. */
+ * a and b are scratch: their contents are unspecified afterwards (partly transformed); c may alias
+ * either.  One read of each factor tile and one write of the product tile between the column passes. */
 int fhe_polymul(fhe_ctx *ctx, uint64_t *d_c, uint64_t *d_a, uint64_t *d_b, const fhe_ntt_tables *t, size_t n_poly,
                 size_t limbs, size_t start_idx, void *stream);
 

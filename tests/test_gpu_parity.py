@@ -266,6 +266,54 @@ def test_polymul_matches_schoolbook(F, eng, O, bits):
         assert (got[0, l] == O.polymul_naive(a[0, l], b[0, l], q)).all()
 
 
+@pytest.mark.parametrize("logn", list(range(1, 18)))
+def test_polymul_every_size_both_paths_and_aliasing(F, eng, O, logn):
+    """fhe_polymul takes the fused route (column passes + one middle launch) for 2^5..2^20 and the plain
+    NTT, NTT, modmul, INTT sequence below that; both against the oracle's NTT-based product (itself
+    pinned to the schoolbook product and the reference's golden vectors)."""
+    N = 1 << logn
+    qs = F.create_moduli(N, [50, 61, 50])
+    t = eng.tables(logn, qs)
+    rng = np.random.default_rng(100 + logn)
+    n_poly = 2 if logn <= 14 else 1
+    a, b = _rand_limbs(rng, qs, N, n_poly), _rand_limbs(rng, qs, N, n_poly)
+    want = np.empty_like(a)
+    sq = np.empty_like(a)
+    for p in range(n_poly):
+        for l, q in enumerate(qs):
+            want[p, l] = O.polymul_ntt(a[p, l], b[p, l], t.psi[l], q)
+            sq[p, l] = O.polymul_ntt(a[p, l], a[p, l], t.psi[l], q)
+    da, db, dc = eng.upload(a), eng.upload(b), eng.upload(np.zeros_like(a))
+    t.polymul(dc, da, db, n_poly=n_poly)                    # separate output
+    assert (dc.download() == want).all()
+    da, db = eng.upload(a), eng.upload(b)
+    t.polymul(da, da, db, n_poly=n_poly)                    # c aliases a
+    assert (da.download() == want).all()
+    da, db = eng.upload(a), eng.upload(b)
+    t.polymul(db, da, db, n_poly=n_poly)                    # c aliases b
+    assert (db.download() == want).all()
+    da = eng.upload(a)
+    t.polymul(dc, da, da, n_poly=n_poly)                    # squaring, both factors one buffer
+    assert (dc.download() == sq).all()
+
+
+def test_polymul_out_of_range_words_and_limb_window(F, eng, O):
+    # arbitrary 64-bit input words are taken modulo their limb's modulus, as everywhere in the engine
+    logn, N = 13, 1 << 13
+    qs = F.create_moduli(N, [50, 50, 61, 61])
+    t = eng.tables(logn, qs)
+    rng = np.random.default_rng(77)
+    start, limbs = 1, 3
+    a = rng.integers(0, 2**64, size=(1, limbs, N), dtype=np.uint64)
+    b = rng.integers(0, 2**64, size=(1, limbs, N), dtype=np.uint64)
+    da, db = eng.upload(a), eng.upload(b)
+    t.polymul(da, da, db, limbs=limbs, start=start)
+    got = da.download()
+    for l in range(limbs):
+        q = qs[start + l]
+        assert (got[0, l] == O.polymul_ntt(a[0, l] % np.uint64(q), b[0, l] % np.uint64(q), t.psi[start + l], q)).all()
+
+
 # ----------------------------------------------------------------------- a8
 def test_base_conversion_against_oracle_large(F, eng, O):
     N = 1 << 12
