@@ -260,9 +260,20 @@ def main():
             O.nwt_forward(a, qs[0], rp)
             reps += 1
         cpu_s = (time.perf_counter() - t) / reps
+        # the reference's own CPU path is pure Python (motivation/ntt.py, rfhe_framewk/src/negaclic_ntt.py):
+        # the oracle's Python restatement of it on the same limb, a few repetitions
+        from oracle import pyport as PY
+        a_list, rp_list = [int(x) for x in a], [int(x) for x in rp]
+        py_reps, t = 0, time.perf_counter()
+        while py_reps < 2 or (time.perf_counter() - t < 6.0 and py_reps < 16):
+            PY.nwt_forward(a_list, qs[0], rp_list)
+            py_reps += 1
+        py_s = (time.perf_counter() - t) / py_reps
         result["cpu_baseline"] = {
             "value": 1.0 / cpu_s, "unit": "NTT/s", "cores": 1, "kind": "port",
             "sample": f"{reps} forward NTTs of one N=2^16 limb (oracle/fhe_oracle.c orc_nwt_forward, u128 mulmod, gcc -O3), ~10 s",
+            "pure_python": {"value": 1.0 / py_s, "unit": "NTT/s", "cores": 1,
+                            "sample": f"{py_reps} forward NTTs of the same limb with oracle/pyport.py nwt_forward (Python integers, the reference's CPU form)"},
         }
     if rank == 0:
         print(json.dumps(result))

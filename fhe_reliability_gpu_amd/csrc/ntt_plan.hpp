@@ -35,7 +35,7 @@ FHE_PLAN(13, 3, 2, 0, 4, 4, 0)
 FHE_PLAN(14, 3, 3, 0, 4, 4, 0)
 FHE_PLAN(15, 4, 3, 0, 4, 4, 0)
 FHE_PLAN(16, 4, 4, 0, 4, 4, 0)
-FHE_PLAN(17, 3, 3, 3, 4, 4, 0)
+FHE_PLAN(17, 4, 4, 0, 3, 3, 3)
 FHE_PLAN(18, 3, 3, 3, 3, 3, 3)
 FHE_PLAN(19, 4, 3, 3, 3, 3, 3)
 FHE_PLAN(20, 4, 3, 3, 4, 3, 3)
