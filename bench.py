@@ -250,6 +250,44 @@ def main():
         }
         result["also"].update(pointwise_rates())
 
+        def keyswitch_rates():
+            # hybrid key switching: random NTT-form input and key, timing only
+            out = {}
+            for name, logn, L, K, dnum, reps in (("keyswitch_N=2^16_L16_K4_dnum4", 16, 16, 4, 4, 10),
+                                                 ("rotate_N=2^14_L4_K1_dnum4 (shape of the reference's SEAL trace, 2543 us on its CPU)", 14, 4, 1, 4, 50)):
+                n = 1 << logn
+                qk = F.create_moduli(n, [args.bits] * (L + K))
+                tk = eng.tables(logn, qk)
+                ks = F.KeySwitch(eng, tk, L, K, dnum)
+                c0 = torch.randint(0, qk[0], (L, n), generator=g, device="cuda", dtype=torch.int64)
+                c1 = torch.randint(0, qk[0], (L, n), generator=g, device="cuda", dtype=torch.int64)
+                evk = torch.randint(0, qk[0], (dnum, 2, L + K, n), generator=g, device="cuda", dtype=torch.int64)
+                o0, o1 = torch.empty_like(c0), torch.empty_like(c0)
+                P = lambda x: C.c_void_p(x.data_ptr())
+                if name.startswith("rotate"):
+                    call = lambda: check(lib.fhe_rotate(eng._h, ks._h, P(o0), P(o1), P(c0), P(c1), 3, P(evk), sptr))
+                else:
+                    call = lambda: check(lib.fhe_keyswitch_apply(eng._h, ks._h, P(o0), P(o1), P(c0), P(evk), sptr))
+                for _ in range(3):
+                    call()
+                torch.cuda.synchronize()
+                e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                t0 = time.perf_counter()
+                e0.record(stream)
+                for _ in range(reps):
+                    call()
+                e1.record(stream)
+                torch.cuda.synchronize()
+                wall = (time.perf_counter() - t0) / reps
+                dev = e0.elapsed_time(e1) / reps
+                # bytes every key switch must move at least once: input, key, two outputs
+                alg = 8.0 * n * (L + dnum * 2 * (L + K) + 2 * L)
+                out[name] = {"us_per_call_device": dev * 1e3, "us_per_call_wall": wall * 1e6,
+                             "frac_of_hbm_roofline (input + key + outputs once)": alg / (dev * 1e-3) / 1e9 / HBM_PEAK_GBS}
+                del ks
+            return out
+        result["also"].update(keyswitch_rates())
+
     if rank == 0 and not args.no_cpu:
         from oracle import cport as O
         rp = O.root_powers(qs[0], LOGN)

@@ -271,7 +271,7 @@ struct BcU64 {
 };
 
 template <int MAXM, class B>
-__global__ __launch_bounds__(256) void k_baseconv_exact(u64 *__restrict__ out, const u64 *__restrict__ in, BaseConvPlanDev pl, u64 N)
+__global__ __launch_bounds__(256) void k_baseconv_exact(u64 *__restrict__ out, const u64 *__restrict__ in, BaseConvPlanDev pl, u64 N, u32 gap_at, u32 gap)
 {
     typedef typename B::acc_t T;
     constexpr int UNR = MAXM <= 8 ? MAXM : 1;   // small bases: digits in registers; larger ones index a scratch array
@@ -306,28 +306,28 @@ __global__ __launch_bounds__(256) void k_baseconv_exact(u64 *__restrict__ out, c
                     B::relax(acc, l, cx);
                 }
             }
-            out[(u64)o * N + i] = B::out(acc, cx);
+            out[(u64)((u32)o < gap_at ? o : o + gap) * N + i] = B::out(acc, cx);
         }
     }
 }
 
 template <class B>
-static void launch_exact(hipStream_t st, dim3 grid, u64 *out, const u64 *in, const BaseConvPlanDev &pl, u64 N)
+static void launch_exact(hipStream_t st, dim3 grid, u64 *out, const u64 *in, const BaseConvPlanDev &pl, u64 N, u32 gap_at, u32 gap)
 {
-    if (pl.m <= 4) hipLaunchKernelGGL((k_baseconv_exact<4, B>), grid, dim3(256), 0, st, out, in, pl, N);
-    else if (pl.m <= 8) hipLaunchKernelGGL((k_baseconv_exact<8, B>), grid, dim3(256), 0, st, out, in, pl, N);
-    else if (pl.m <= 16) hipLaunchKernelGGL((k_baseconv_exact<16, B>), grid, dim3(256), 0, st, out, in, pl, N);
-    else if (pl.m <= 32) hipLaunchKernelGGL((k_baseconv_exact<32, B>), grid, dim3(256), 0, st, out, in, pl, N);
-    else hipLaunchKernelGGL((k_baseconv_exact<64, B>), grid, dim3(256), 0, st, out, in, pl, N);
+    if (pl.m <= 4) hipLaunchKernelGGL((k_baseconv_exact<4, B>), grid, dim3(256), 0, st, out, in, pl, N, gap_at, gap);
+    else if (pl.m <= 8) hipLaunchKernelGGL((k_baseconv_exact<8, B>), grid, dim3(256), 0, st, out, in, pl, N, gap_at, gap);
+    else if (pl.m <= 16) hipLaunchKernelGGL((k_baseconv_exact<16, B>), grid, dim3(256), 0, st, out, in, pl, N, gap_at, gap);
+    else if (pl.m <= 32) hipLaunchKernelGGL((k_baseconv_exact<32, B>), grid, dim3(256), 0, st, out, in, pl, N, gap_at, gap);
+    else hipLaunchKernelGGL((k_baseconv_exact<64, B>), grid, dim3(256), 0, st, out, in, pl, N, gap_at, gap);
 }
 
-hipError_t launch_baseconv_exact(hipStream_t st, u64 *out, const u64 *in, const BaseConvPlanDev &pl, u64 N)
+hipError_t launch_baseconv_exact(hipStream_t st, u64 *out, const u64 *in, const BaseConvPlanDev &pl, u64 N, u32 gap_at, u32 gap)
 {
     if (pl.m > BC_MAX_LIMBS) return hipErrorInvalidValue;
     u64 want = (N + 255) / 256;
     const dim3 grid((u32)(want > 16384 ? 16384 : want));
-    if (pl.f64) launch_exact<BcF64>(st, grid, out, in, pl, N);
-    else launch_exact<BcU64>(st, grid, out, in, pl, N);
+    if (pl.f64) launch_exact<BcF64>(st, grid, out, in, pl, N, gap_at, gap);
+    else launch_exact<BcU64>(st, grid, out, in, pl, N, gap_at, gap);
     return hipGetLastError();
 }
 
@@ -423,6 +423,81 @@ hipError_t launch_sub_scale(hipStream_t st, u64 *out, const u64 *a, const u64 *b
     if (!total) return hipSuccess;
     u64 want = (total + 255) / 256;
     hipLaunchKernelGGL(k_sub_scale, dim3((u32)(want > 8192 ? 8192 : want)), dim3(256), 0, st, out, a, b, scal, lp, limb0, limbs, logn);
+    return hipGetLastError();
+}
+
+// ---------------------------------------------------------------------------
+// Key-switch inner product (MULTEVK): acc_h[j] = sum_d ext_d[j] * evk[d][h][j] mod q_j for both key halves in one
+// pass: every extended digit is read once, nothing is read-modify-written.  ext_d[j] is the digit's own
+// NTT-form input limb when j belongs to digit d, the base-extended + transformed limb otherwise.
+// ---------------------------------------------------------------------------
+struct KsMacF64 {
+    typedef double acc_t;
+    static __device__ __forceinline__ double zero() { return 0.0; }
+    static __device__ __forceinline__ void mac(double &s, u64 x, u64 y, int term, const LimbParams &p)
+    {
+        const ArithF64::Ctx c = ArithF64::make_ctx(p);
+        const double a = ArithF64::from_canonical(x < p.q ? x : reduce_any_u64(x, p.q));
+        const double b = ArithF64::from_canonical(y < p.q ? y : reduce_any_u64(y, p.q));
+        const double h = a * b;
+        const double k = __builtin_rint(a * (b * c.ninv));
+        const double l = __builtin_fma(a, b, -h);
+        s += __builtin_fma(-k, c.n, h) + l;          // |term| < 0.875 q
+        if ((term & 7) == 7) ArithF64::reduce(s, c);
+    }
+    static __device__ __forceinline__ u64 out(double s, const LimbParams &p) { return ArithF64::canonical(s, ArithF64::make_ctx(p)); }
+};
+struct KsMacU64 {
+    struct acc_t {
+        u64 lo, hi;
+    };
+    static __device__ __forceinline__ acc_t zero() { return acc_t{0, 0}; }
+    static __device__ __forceinline__ void mac(acc_t &s, u64 x, u64 y, int term, const LimbParams &p)
+    {
+        x = x < p.q ? x : reduce_any_u64(x, p.q);
+        y = y < p.q ? y : reduce_any_u64(y, p.q);
+        const u64 lo = x * y, hi = __umul64hi(x, y);      // < 2^124
+        s.lo += lo;
+        s.hi += hi + (s.lo < lo);
+        if ((term & 7) == 7) s = acc_t{barrett128(s.lo, s.hi, p.q, p.barrett_lo, p.barrett_hi), 0};
+    }
+    static __device__ __forceinline__ u64 out(const acc_t &s, const LimbParams &p) { return barrett128(s.lo, s.hi, p.q, p.barrett_lo, p.barrett_hi); }
+};
+
+template <class K>
+__device__ __forceinline__ void ks_mac_limb(const KsMacArgs &a, u32 j, u64 i, const LimbParams &p)
+{
+    const u64 N = (u64)1 << a.logn;
+    typename K::acc_t s0 = K::zero(), s1 = K::zero();
+    for (u32 d = 0; d < a.dnum; d++) {
+        const u32 lo = d * a.alpha, hi = lo + a.alpha < a.L ? lo + a.alpha : a.L;
+        const u64 x = (j >= lo && j < hi) ? a.c[(u64)j * N + i] : a.ext[((u64)d * a.M + j) * N + i];
+        const u64 *key = a.evk + ((u64)d * 2 * a.M + j) * N + i;
+        K::mac(s0, x, key[0], (int)d, p);
+        K::mac(s1, x, key[(u64)a.M * N], (int)d, p);
+    }
+    a.acc[(u64)j * N + i] = K::out(s0, p);
+    a.acc[((u64)a.M + j) * N + i] = K::out(s1, p);
+}
+
+__global__ __launch_bounds__(256) void k_ks_mac(KsMacArgs a)
+{
+    const u64 total = (u64)a.M << a.logn;
+    for (u64 e = blockIdx.x * (u64)blockDim.x + threadIdx.x; e < total; e += (u64)gridDim.x * blockDim.x) {
+        const u32 j = (u32)(e >> a.logn);
+        const u64 i = e & (((u64)1 << a.logn) - 1);
+        const LimbParams &p = a.lp[j];
+        if (p.path == PATH_F64) ks_mac_limb<KsMacF64>(a, j, i, p);
+        else ks_mac_limb<KsMacU64>(a, j, i, p);
+    }
+}
+
+hipError_t launch_ks_mac(hipStream_t st, const KsMacArgs &a)
+{
+    const u64 total = (u64)a.M << a.logn;
+    if (!total) return hipSuccess;
+    const u64 want = (total + 255) / 256;
+    hipLaunchKernelGGL(k_ks_mac, dim3((u32)(want > 16384 ? 16384 : want)), dim3(256), 0, st, a);
     return hipGetLastError();
 }
 

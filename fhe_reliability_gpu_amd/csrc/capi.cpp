@@ -126,7 +126,9 @@ struct fhe_keyswitch {
     std::vector<fhe_baseconv *> up;     // per digit: digit primes -> every other prime (ascending index)
     fhe_baseconv *down = nullptr;       // P -> Q
     DevBuf pinv;                        // P^-1 mod q_j, j < L
-    DevBuf coef, ext, tmp, acc0, acc1, tP, conv, rot;
+    DevBuf coef, ext, acc, conv, rot;  // coef [L][N], ext [dnum][M][N], acc [2][M][N], conv [2][L][N]
+    DevBuf ext_map[2];                 // per arithmetic path: the limbs of ext the forward transform covers
+    u32 ext_units[2] = {0, 0};
     ~fhe_keyswitch()
     {
         for (auto *b : up) fhe_baseconv_destroy(b);
@@ -959,13 +961,21 @@ int fhe_keyswitch_create(fhe_ctx *ctx, const fhe_ntt_tables *t, int L, int K, in
         HIP_TRY(hipSetDevice(ctx->device));
         HIP_TRY(p->pinv.upload(pinv));
     }
+    // every limb of every digit's extension except the digit's own limbs, one list per arithmetic path
+    for (int path = 0; path < 2; path++) {
+        std::vector<UnitRef> map;
+        for (int d = 0; d < dnum; d++) {
+            const int lo = d * p->alpha, hi = std::min(L, lo + p->alpha);
+            for (size_t j = 0; j < M; j++)
+                if (((int)j < lo || (int)j >= hi) && t->path[j] == path) map.push_back(UnitRef{(u32)(d * M + j), (u32)j});
+        }
+        p->ext_units[path] = (u32)map.size();
+        if (!map.empty()) HIP_TRY(p->ext_map[path].upload(map));
+    }
     HIP_TRY(p->coef.alloc(L * N * 8));
-    HIP_TRY(p->ext.alloc(M * N * 8));
-    HIP_TRY(p->tmp.alloc(M * N * 8));
-    HIP_TRY(p->acc0.alloc(M * N * 8));
-    HIP_TRY(p->acc1.alloc(M * N * 8));
-    HIP_TRY(p->tP.alloc((size_t)K * N * 8));
-    HIP_TRY(p->conv.alloc(L * N * 8));
+    HIP_TRY(p->ext.alloc((size_t)dnum * M * N * 8));
+    HIP_TRY(p->acc.alloc(2 * M * N * 8));
+    HIP_TRY(p->conv.alloc(2 * (size_t)L * N * 8));
     HIP_TRY(p->rot.alloc(3 * (size_t)L * N * 8));
     *out = p.release();
     return FHE_OK;
@@ -997,6 +1007,10 @@ int fhe_keyswitch_destroy(fhe_keyswitch *p)
     return FHE_OK;
 }
 
+// Hybrid RNS key switching, operation order of the reference's SEAL trace (profile_framewk/build/data/ckks/16384_4:466-539)
+// with the launches batched: one INTT, one base extension per digit written straight into the [dnum][M][N]
+// layout, ONE forward transform over every extended limb of every digit (unit list), ONE inner-product launch
+// for all digits and both key halves, and a mod-down that handles both halves per launch where the layout allows.
 int fhe_keyswitch_apply(fhe_ctx *ctx, fhe_keyswitch *p, uint64_t *d_out0, uint64_t *d_out1, const uint64_t *d_c,
                         const uint64_t *d_evk, void *stream)
 {
@@ -1005,48 +1019,59 @@ int fhe_keyswitch_apply(fhe_ctx *ctx, fhe_keyswitch *p, uint64_t *d_out0, uint64
     hipStream_t st = pick(ctx, stream);
     const fhe_ntt_tables *t = p->t;
     const size_t N = (size_t)1 << p->log_n, L = p->L, K = p->K, M = L + K;
-    u64 *coef = p->coef.as<u64>(), *ext = p->ext.as<u64>(), *tmp = p->tmp.as<u64>();
-    u64 *acc[2] = {p->acc0.as<u64>(), p->acc1.as<u64>()};
+    const LimbParams *lp = t->d_lp.as<LimbParams>();
+    u64 *coef = p->coef.as<u64>(), *ext = p->ext.as<u64>(), *acc = p->acc.as<u64>(), *conv = p->conv.as<u64>();
     int rc;
+    hipError_t e;
     TraceScope tr_ks(ctx, st, "KEYSWITCH");
     // INTT of the L input limbs (the "3 INTT" that open KEYSWITCH in the L=4 trace, 16384_4:468-470)
     HIP_TRY(hipMemcpyAsync(coef, d_c, L * N * 8, hipMemcpyDeviceToDevice, st));
     if ((rc = ntt_batch(ctx, coef, t, 1, L, 0, st, true))) return rc;
-    HIP_TRY(hipMemsetAsync(acc[0], 0, M * N * 8, st));
-    HIP_TRY(hipMemsetAsync(acc[1], 0, M * N * 8, st));
-    for (int d = 0; d < p->dnum; d++) {
-        const size_t lo = (size_t)d * p->alpha, hi = std::min(L, lo + (size_t)p->alpha);
-        // base extension of the digit to every other prime (MODREDUCTION, 16384_4:471-452), coefficient domain
-        {
+    {
+        // base extension of each digit to every other prime (MODREDUCTION, 16384_4:471-452), then their transforms
+        // (one trace line for the phase; the nested NTT line precedes it, as the reference's tools expect of nested costs)
         TraceScope tr_mr(ctx, st, "MODREDUCTION");
-        if ((rc = fhe_baseconv_exact(ctx, tmp, coef + lo * N, p->up[d], N, st))) return rc;
-        if (lo) HIP_TRY(hipMemcpyAsync(ext, tmp, lo * N * 8, hipMemcpyDeviceToDevice, st));
-        if (hi < M) HIP_TRY(hipMemcpyAsync(ext + hi * N, tmp + lo * N, (M - hi) * N * 8, hipMemcpyDeviceToDevice, st));
-        // NTT of the extended limbs; the digit's own limbs are already in NTT form in the input
-        if (lo && (rc = ntt_batch(ctx, ext, t, 1, lo, 0, st, false))) return rc;
-        if (hi < M && (rc = ntt_batch(ctx, ext + hi * N, t, 1, M - hi, hi, st, false))) return rc;
-        HIP_TRY(hipMemcpyAsync(ext + lo * N, d_c + lo * N, (hi - lo) * N * 8, hipMemcpyDeviceToDevice, st));
+        for (int d = 0; d < p->dnum; d++) {
+            const size_t lo = (size_t)d * p->alpha, hi = std::min(L, lo + (size_t)p->alpha);
+            e = launch_baseconv_exact(st, ext + (size_t)d * M * N, coef + lo * N, p->up[d]->dev, N, (u32)lo, (u32)(hi - lo));
+            if (e != hipSuccess) return hip_fail(e, "launch_baseconv_exact");
         }
-        // multiply-accumulate with the evaluation key of this digit (MULTEVALK)
+        TraceScope tr_ntt(ctx, st, "NTT");
+        for (int path = 0; path < 2; path++) {
+            if (!p->ext_units[path]) continue;
+            PassArgs a{ext, lp, 0u, 1u, p->ext_units[path], 1u, p->ext_map[path].as<UnitRef>()};
+            if ((e = launch_ntt(st, a, p->log_n, false, path, 1)) != hipSuccess) return hip_fail(e, "launch_ntt");
+        }
+    }
+    {
+        // multiply-accumulate with the evaluation key (MULTEVK): all digits, both halves, one launch
         TraceScope tr_mk(ctx, st, "MULTEVK");
-        for (int h = 0; h < 2; h++) {
-            const u64 *key = d_evk + ((size_t)d * 2 + h) * M * N;
-            if ((rc = pointwise(ctx, acc[h], ext, key, t, 1, M, 0, st, true))) return rc;
-        }
+        const KsMacArgs ka{acc, ext, d_c, d_evk, lp, (u32)L, (u32)M, (u32)p->dnum, (u32)p->alpha, p->log_n};
+        if ((e = launch_ks_mac(st, ka)) != hipSuccess) return hip_fail(e, "launch_ks_mac");
     }
     // mod-down by P (MODSWITCH, 16384_4:454-463): INTT of the special limbs, conversion to Q, NTT, subtract, times P^-1
     TraceScope tr_ms(ctx, st, "MODSWITCH");
+    {
+        // the K special limbs of both halves, in place inside acc ([2][M][N], polynomial stride M)
+        TraceScope tr_ntt(ctx, st, "NTT");
+        rc = for_each_run(t, K, L, [&](size_t off, size_t len, int path) -> int {
+            PassArgs a{acc + (L + off) * N, lp, (u32)(L + off), (u32)len, (u32)(2 * len), (u32)M, nullptr};
+            hipError_t e2 = launch_ntt(st, a, p->log_n, true, path, 1);
+            return e2 == hipSuccess ? FHE_OK : hip_fail(e2, "launch_ntt");
+        });
+        if (rc) return rc;
+    }
     u64 *outs[2] = {d_out0, d_out1};
     for (int h = 0; h < 2; h++) {
-        u64 *tP = p->tP.as<u64>(), *conv = p->conv.as<u64>();
-        HIP_TRY(hipMemcpyAsync(tP, acc[h] + L * N, K * N * 8, hipMemcpyDeviceToDevice, st));
-        if ((rc = ntt_batch(ctx, tP, t, 1, K, L, st, true))) return rc;
+        u64 *tP = acc + ((size_t)h * M + L) * N;
         // BGV: remove delta = t * [acc * t^-1]_P instead of [acc]_P, so that delta = 0 mod t
         if (p->plain_modulus && (rc = fhe_scalar_affine(ctx, tP, tP, p->t_inv_P.data(), nullptr, t, 1, K, L, st))) return rc;
-        if ((rc = fhe_baseconv_exact(ctx, conv, tP, p->down, N, st))) return rc;
-        if (p->plain_modulus && (rc = fhe_scalar_affine(ctx, conv, conv, p->t_mod_Q.data(), nullptr, t, 1, L, 0, st))) return rc;
-        if ((rc = ntt_batch(ctx, conv, t, 1, L, 0, st, false))) return rc;
-        hipError_t e = launch_sub_scale(st, outs[h], acc[h], conv, p->pinv.as<u64>(), t->d_lp.as<LimbParams>(), 0, (u32)L, p->log_n);
+        if ((e = launch_baseconv_exact(st, conv + (size_t)h * L * N, tP, p->down->dev, N)) != hipSuccess) return hip_fail(e, "launch_baseconv_exact");
+    }
+    if (p->plain_modulus && (rc = fhe_scalar_affine(ctx, conv, conv, p->t_mod_Q.data(), nullptr, t, 2, L, 0, st))) return rc;
+    if ((rc = ntt_batch(ctx, conv, t, 2, L, 0, st, false))) return rc;
+    for (int h = 0; h < 2; h++) {
+        e = launch_sub_scale(st, outs[h], acc + (size_t)h * M * N, conv + (size_t)h * L * N, p->pinv.as<u64>(), lp, 0, (u32)L, p->log_n);
         if (e != hipSuccess) return hip_fail(e, "launch_sub_scale");
     }
     return FHE_OK;

@@ -82,7 +82,21 @@ struct BaseConvPlanDev {
     const u64 *fast_coef;     // m x k   (Phat_j * inv_j) mod q_o   (rfhe_framewk/src/baseConv.py:17-29)
     const u64 *fast_coef_shoup;
 };
-hipError_t launch_baseconv_exact(hipStream_t st, u64 *out, const u64 *in, const BaseConvPlanDev &pl, u64 N);
+// output limb o is written at limb index o (o < gap_at) or o + gap: lets a key-switch digit's extension land
+// in the [M][N] layout with the digit's own limbs skipped
+hipError_t launch_baseconv_exact(hipStream_t st, u64 *out, const u64 *in, const BaseConvPlanDev &pl, u64 N, u32 gap_at = 0xFFFFFFFFu,
+                                 u32 gap = 0);
+// key-switch inner product over all digits and both key halves (aux_kernels.hip k_ks_mac)
+struct KsMacArgs {
+    u64 *acc;            // [2][M][N]
+    const u64 *ext;      // [dnum][M][N]  extended digits, NTT form (own limbs unused)
+    const u64 *c;        // [L][N]        input, NTT form
+    const u64 *evk;      // [dnum][2][M][N]
+    const LimbParams *lp;
+    u32 L, M, dnum, alpha;
+    int logn;
+};
+hipError_t launch_ks_mac(hipStream_t st, const KsMacArgs &a);
 hipError_t launch_bconv_fast(hipStream_t st, u64 *out, const u64 *in, const BaseConvPlanDev &pl, u64 N);
 hipError_t launch_crt_garner(hipStream_t st, u64 *x_lo, u64 *x_hi, const u64 *residues, const u64 *moduli,
                              const u64 *ratios, const u64 *pref_lo, const u64 *pref_hi, const u64 *inv_pref, int m, u64 N);

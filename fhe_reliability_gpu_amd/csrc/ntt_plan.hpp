@@ -78,6 +78,12 @@ template <int LOGN, int GEO = 0> struct PlanGeom {
     static constexpr int TR = !TWO_PASS ? 1 : PR <= 8 ? 16 : PR == 9 ? 8 : 4;
 };
 
+// Entry of an explicit unit list: where the limb-polynomial starts (in units of N words from `data`) and
+// which table limb it belongs to.
+struct UnitRef {
+    u32 off, limb;
+};
+
 // What a pass needs to know about the launch.
 struct PassArgs {
     u64 *data;              // [n_poly][limbs][N]
@@ -86,6 +92,8 @@ struct PassArgs {
     u32 limbs;              // limbs of each polynomial handled by this launch (same arithmetic path)
     u32 units;              // n_poly * limbs
     u32 poly_stride;        // distance between polynomials in units of one limb (>= limbs)
+    const UnitRef *map;     // optional (two-launch path): units[] given explicitly instead of the [poly][limb] grid --
+                            // e.g. "every limb of every key-switch digit except the digit's own" in one launch
 };
 
 template <class A, int LOGN, bool INVERSE, int GEO = 0>
@@ -130,6 +138,11 @@ template <class CP, int LOGN>
 FHE_D u64 *col_tile(u32 block, const PassArgs &a, u32 &limb)
 {
     const u32 unit = block / CP::TILES, tile = block % CP::TILES;
+    if (a.map) {
+        const UnitRef m = a.map[unit];
+        limb = m.limb;
+        return a.data + ((size_t)m.off << LOGN) + (size_t)tile * CP::TCOLS;
+    }
     const u32 polys = a.units / a.limbs;
     const u32 l = unit / polys, poly = unit % polys;
     limb = a.limb0 + l;
@@ -139,10 +152,15 @@ template <class RP, int LOGN>
 FHE_D u64 *row_tile(u32 block, const PassArgs &a, u32 &limb, u32 &row0)
 {
     const u32 unit = block / RP::TILES, tile = block % RP::TILES;
+    row0 = tile * RP::TROWS;
+    if (a.map) {
+        const UnitRef m = a.map[unit];
+        limb = m.limb;
+        return a.data + ((size_t)m.off << LOGN) + (size_t)row0 * RP::NPTS;
+    }
     const u32 polys = a.units / a.limbs;
     const u32 l = unit / polys, poly = unit % polys;
     limb = a.limb0 + l;
-    row0 = tile * RP::TROWS;
     return a.data + (((size_t)poly * a.poly_stride + l) << LOGN) + (size_t)row0 * RP::NPTS;
 }
 
