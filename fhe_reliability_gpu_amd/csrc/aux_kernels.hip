@@ -270,64 +270,147 @@ struct BcU64 {
     static __device__ __forceinline__ u64 out(u64 a, const Ctx &) { return a; }
 };
 
-template <int MAXM, class B>
-__global__ __launch_bounds__(256) void k_baseconv_exact(u64 *__restrict__ out, const u64 *__restrict__ in, BaseConvPlanDev pl, u64 N, u32 gap_at, u32 gap)
+template <int MAXM, class B, bool STAGE_>
+__device__ __forceinline__ void bc_exact_body(const BcJob &job, u64 N, u32 oc)
 {
     typedef typename B::acc_t T;
     constexpr int UNR = MAXM <= 8 ? MAXM : 1;   // small bases: digits in registers; larger ones index a scratch array
+    // Short launches of small bases (N = 2^16: a single wave of workgroups) stage their constants in LDS once per
+    // workgroup: read through scalar loads inside the loops they were bound by those loads' round trips.  Long
+    // launches keep the scalar loads (operands in SGPRs cost nothing once other waves hide the latency).
+    constexpr bool STAGE = STAGE_ && MAXM <= 8;
+    constexpr int OCMAX = 64;
+    __shared__ Tw s_dig[STAGE ? MAXM * MAXM : 1], s_hor[STAGE ? MAXM * OCMAX : 1], s_fpi[STAGE ? MAXM : 1], s_fpo[STAGE ? OCMAX : 1];
+    __shared__ u64 s_pi[STAGE ? MAXM : 1], s_qo[STAGE ? OCMAX : 1];
+    const BaseConvPlanDev &pl = job.pl;
+    const u64 *__restrict__ in = job.in;
+    u64 *__restrict__ out = job.out;
     const int m = pl.m, k = pl.k;
-    const Tw FHE_GLOBAL *dig = (const Tw FHE_GLOBAL *)pl.dig, *hor = (const Tw FHE_GLOBAL *)pl.hor;
-    const Tw FHE_GLOBAL *fp_in = (const Tw FHE_GLOBAL *)pl.fp_in, *fp_out = (const Tw FHE_GLOBAL *)pl.fp_out;
-    const u64 FHE_GLOBAL *mod_in = (const u64 FHE_GLOBAL *)pl.mod_in, *mod_out = (const u64 FHE_GLOBAL *)pl.mod_out;
+    // the plan's tables are never written by a kernel: constant address space, so uniform reads become scalar loads
+    // whatever the compiler can or cannot prove about `out`
+    const Tw FHE_CONSTANT *dig = (const Tw FHE_CONSTANT *)(__UINTPTR_TYPE__)pl.dig, *hor = (const Tw FHE_CONSTANT *)(__UINTPTR_TYPE__)pl.hor;
+    const Tw FHE_CONSTANT *fp_in = (const Tw FHE_CONSTANT *)(__UINTPTR_TYPE__)pl.fp_in, *fp_out = (const Tw FHE_CONSTANT *)(__UINTPTR_TYPE__)pl.fp_out;
+    const u64 FHE_CONSTANT *mod_in = (const u64 FHE_CONSTANT *)(__UINTPTR_TYPE__)pl.mod_in, *mod_out = (const u64 FHE_CONSTANT *)(__UINTPTR_TYPE__)pl.mod_out;
+    // blockIdx.y selects a slice of the outputs (the digits are cheap to recompute; small N needs the extra workgroups)
+    const int o0 = (int)blockIdx.y * (int)oc, o1 = o0 + (int)oc < k ? o0 + (int)oc : k;
+    if (STAGE) {
+        const int cnt = o1 - o0;
+        for (int t = threadIdx.x; t < m * m; t += blockDim.x) s_dig[(t / m) * MAXM + t % m] = dig[t];
+        for (int t = threadIdx.x; t < m * cnt; t += blockDim.x) s_hor[(t / cnt) * OCMAX + t % cnt] = hor[(t / cnt) * k + o0 + t % cnt];
+        for (int t = threadIdx.x; t < m; t += blockDim.x) {
+            s_fpi[t] = fp_in[t];
+            s_pi[t] = mod_in[t];
+        }
+        for (int t = threadIdx.x; t < cnt; t += blockDim.x) {
+            s_fpo[t] = fp_out[o0 + t];
+            s_qo[t] = mod_out[o0 + t];
+        }
+        __syncthreads();
+    }
+    auto c_dig = [&](int l, int j) -> Tw { if (STAGE) return s_dig[l * MAXM + j]; const Tw t = dig[l * m + j]; return t; };
+    auto c_hor = [&](int l, int o) -> Tw { if (STAGE) return s_hor[l * OCMAX + o - o0]; const Tw t = hor[l * k + o]; return t; };
+    auto c_fpi = [&](int j) -> Tw { if (STAGE) return s_fpi[j]; const Tw t = fp_in[j]; return t; };
+    auto c_fpo = [&](int o) -> Tw { if (STAGE) return s_fpo[o - o0]; const Tw t = fp_out[o]; return t; };
     for (u64 i = blockIdx.x * (u64)blockDim.x + threadIdx.x; i < N; i += (u64)gridDim.x * blockDim.x) {
         T c[MAXM];
 #pragma unroll UNR
         for (int j = 0; j < MAXM; j++) {
             if (j < m) {
-                const u64 pj = mod_in[j];
-                const auto cx = B::ctx(pj, fp_in[j]);
-                T t = B::mul(B::load(in[(u64)j * N + i], pj), dig[j * m + j], cx);
+                const u64 pj = STAGE ? s_pi[j] : mod_in[j];
+                const auto cx = B::ctx(pj, c_fpi(j));
+                T t = B::mul(B::load(in[(u64)j * N + i], pj), c_dig(j, j), cx);
 #pragma unroll UNR
                 for (int l = 0; l < j; l++) {
-                    t = B::sub(t, B::mul(c[l], dig[l * m + j], cx), cx);
+                    t = B::sub(t, B::mul(c[l], c_dig(l, j), cx), cx);
                     B::relax(t, l + 1, cx);
                 }
                 c[j] = B::digit(t, cx);
             }
         }
-        for (int o = 0; o < k; o++) {
-            const u64 q = mod_out[o];
-            const auto cx = B::ctx(q, fp_out[o]);
-            T acc = B::mul(c[0], hor[o], cx);
+        for (int o = o0; o < o1; o++) {
+            const u64 q = STAGE ? s_qo[o - o0] : mod_out[o];
+            const auto cx = B::ctx(q, c_fpo(o));
+            T acc = B::mul(c[0], c_hor(0, o), cx);
 #pragma unroll UNR
             for (int l = 1; l < MAXM; l++) {
                 if (l < m) {
-                    acc = B::add(acc, B::mul(c[l], hor[l * k + o], cx), cx);
+                    acc = B::add(acc, B::mul(c[l], c_hor(l, o), cx), cx);
                     B::relax(acc, l, cx);
                 }
             }
-            out[(u64)((u32)o < gap_at ? o : o + gap) * N + i] = B::out(acc, cx);
+            out[(u64)((u32)o < job.gap_at ? o : o + job.gap) * N + i] = B::out(acc, cx);
         }
     }
 }
 
-template <class B>
-static void launch_exact(hipStream_t st, dim3 grid, u64 *out, const u64 *in, const BaseConvPlanDev &pl, u64 N, u32 gap_at, u32 gap)
+// one conversion, job passed by value
+template <int MAXM, class B, bool STAGE>
+__global__ __launch_bounds__(256) void k_baseconv_exact(BcJob job, u64 N, u32 oc)
 {
-    if (pl.m <= 4) hipLaunchKernelGGL((k_baseconv_exact<4, B>), grid, dim3(256), 0, st, out, in, pl, N, gap_at, gap);
-    else if (pl.m <= 8) hipLaunchKernelGGL((k_baseconv_exact<8, B>), grid, dim3(256), 0, st, out, in, pl, N, gap_at, gap);
-    else if (pl.m <= 16) hipLaunchKernelGGL((k_baseconv_exact<16, B>), grid, dim3(256), 0, st, out, in, pl, N, gap_at, gap);
-    else if (pl.m <= 32) hipLaunchKernelGGL((k_baseconv_exact<32, B>), grid, dim3(256), 0, st, out, in, pl, N, gap_at, gap);
-    else hipLaunchKernelGGL((k_baseconv_exact<64, B>), grid, dim3(256), 0, st, out, in, pl, N, gap_at, gap);
+    bc_exact_body<MAXM, B, STAGE>(job, N, oc);
+}
+// several conversions of the same shape class in one launch (key-switch digits, the two halves of a mod-down):
+// blockIdx.z picks the job from a device-resident list
+template <int MAXM, class B, bool STAGE>
+__global__ __launch_bounds__(256) void k_baseconv_exact_jobs(const BcJob *jobs, u64 N, u32 oc)
+{
+    const BcJob job = jobs[blockIdx.z];
+    bc_exact_body<MAXM, B, STAGE>(job, N, oc);
+}
+
+template <class B>
+static void launch_exact(hipStream_t st, dim3 grid, const BcJob *dev_jobs, const BcJob &job, int maxm, u64 N, u32 oc)
+{
+#define FHE_BC(MM)                                                                                                    \
+    do {                                                                                                              \
+        const bool stage = MM <= 8 && (u64)grid.x * grid.y * grid.z <= 8192;                                           \
+        if (dev_jobs && stage) hipLaunchKernelGGL((k_baseconv_exact_jobs<MM, B, true>), grid, dim3(256), 0, st, dev_jobs, N, oc);  \
+        else if (dev_jobs) hipLaunchKernelGGL((k_baseconv_exact_jobs<MM, B, false>), grid, dim3(256), 0, st, dev_jobs, N, oc);     \
+        else if (stage) hipLaunchKernelGGL((k_baseconv_exact<MM, B, true>), grid, dim3(256), 0, st, job, N, oc);        \
+        else hipLaunchKernelGGL((k_baseconv_exact<MM, B, false>), grid, dim3(256), 0, st, job, N, oc);                  \
+    } while (0)
+    if (maxm <= 4) FHE_BC(4);
+    else if (maxm <= 8) FHE_BC(8);
+    else if (maxm <= 16) FHE_BC(16);
+    else if (maxm <= 32) FHE_BC(32);
+    else FHE_BC(64);
+#undef FHE_BC
+}
+
+// aim at >= 2048 workgroups: slice the k outputs over blockIdx.y while a slice stays at least as large as the
+// digit computation it repeats (m/2 products per digit on average)
+static u32 bc_slices(u32 gx, u32 jobs, int m, int k)
+{
+    u32 slices = 1;
+    while (gx * jobs * slices < 2048 && slices * 2 <= (u32)k && (u32)k / (slices * 2) >= (u32)(m + 1) / 2) slices *= 2;
+    return slices;
 }
 
 hipError_t launch_baseconv_exact(hipStream_t st, u64 *out, const u64 *in, const BaseConvPlanDev &pl, u64 N, u32 gap_at, u32 gap)
 {
     if (pl.m > BC_MAX_LIMBS) return hipErrorInvalidValue;
     u64 want = (N + 255) / 256;
-    const dim3 grid((u32)(want > 16384 ? 16384 : want));
-    if (pl.f64) launch_exact<BcF64>(st, grid, out, in, pl, N, gap_at, gap);
-    else launch_exact<BcU64>(st, grid, out, in, pl, N, gap_at, gap);
+    const u32 gx = (u32)(want > 16384 ? 16384 : want);
+    const u32 slices = bc_slices(gx, 1, pl.m, pl.k), oc = ((u32)pl.k + slices - 1) / slices;
+    const dim3 grid(gx, ((u32)pl.k + oc - 1) / oc);
+    const BcJob job{pl, in, out, gap_at, gap};
+    if (pl.f64) launch_exact<BcF64>(st, grid, nullptr, job, pl.m, N, oc);
+    else launch_exact<BcU64>(st, grid, nullptr, job, pl.m, N, oc);
+    return hipGetLastError();
+}
+
+// jobs: device array of n_jobs entries that share the arithmetic path (f64) ; max_m / max_k = largest m / k among them
+hipError_t launch_baseconv_exact_jobs(hipStream_t st, const BcJob *dev_jobs, u32 n_jobs, int max_m, int max_k, bool f64, u64 N)
+{
+    if (!n_jobs) return hipSuccess;
+    if (max_m > BC_MAX_LIMBS || n_jobs > 65535) return hipErrorInvalidValue;
+    u64 want = (N + 255) / 256;
+    const u32 gx = (u32)(want > 16384 ? 16384 : want);
+    const u32 slices = bc_slices(gx, n_jobs, max_m, max_k), oc = ((u32)max_k + slices - 1) / slices;
+    const dim3 grid(gx, ((u32)max_k + oc - 1) / oc, n_jobs);
+    const BcJob none{};
+    if (f64) launch_exact<BcF64>(st, grid, dev_jobs, none, max_m, N, oc);
+    else launch_exact<BcU64>(st, grid, dev_jobs, none, max_m, N, oc);
     return hipGetLastError();
 }
 

@@ -127,6 +127,9 @@ struct fhe_keyswitch {
     fhe_baseconv *down = nullptr;       // P -> Q
     DevBuf pinv;                        // P^-1 mod q_j, j < L
     DevBuf coef, ext, acc, conv, rot;  // coef [L][N], ext [dnum][M][N], acc [2][M][N], conv [2][L][N]
+    DevBuf up_jobs, down_jobs;         // device job lists: all digit extensions / both mod-down conversions in one launch each
+    int up_max_m = 0, up_max_k = 0;
+    bool up_batched = false;           // every digit plan on the same arithmetic path
     DevBuf ext_map[2];                 // per arithmetic path: the limbs of ext the forward transform covers
     u32 ext_units[2] = {0, 0};
     ~fhe_keyswitch()
@@ -977,6 +980,22 @@ int fhe_keyswitch_create(fhe_ctx *ctx, const fhe_ntt_tables *t, int L, int K, in
     HIP_TRY(p->acc.alloc(2 * M * N * 8));
     HIP_TRY(p->conv.alloc(2 * (size_t)L * N * 8));
     HIP_TRY(p->rot.alloc(3 * (size_t)L * N * 8));
+    {
+        std::vector<BcJob> up, down;
+        p->up_batched = true;
+        for (int d = 0; d < dnum; d++) {
+            const size_t lo = (size_t)d * p->alpha, hi = std::min((size_t)L, lo + (size_t)p->alpha);
+            const BaseConvPlanDev &pl = p->up[d]->dev;
+            up.push_back(BcJob{pl, p->coef.as<u64>() + lo * N, p->ext.as<u64>() + (size_t)d * M * N, (u32)lo, (u32)(hi - lo)});
+            p->up_max_m = std::max(p->up_max_m, pl.m);
+            p->up_max_k = std::max(p->up_max_k, pl.k);
+            p->up_batched = p->up_batched && pl.f64 == p->up[0]->dev.f64;
+        }
+        for (int h = 0; h < 2; h++)
+            down.push_back(BcJob{p->down->dev, p->acc.as<u64>() + ((size_t)h * M + L) * N, p->conv.as<u64>() + (size_t)h * L * N, 0xFFFFFFFFu, 0u});
+        HIP_TRY(p->up_jobs.upload(up));
+        HIP_TRY(p->down_jobs.upload(down));
+    }
     *out = p.release();
     return FHE_OK;
 }
@@ -1031,10 +1050,15 @@ int fhe_keyswitch_apply(fhe_ctx *ctx, fhe_keyswitch *p, uint64_t *d_out0, uint64
         // base extension of each digit to every other prime (MODREDUCTION, 16384_4:471-452), then their transforms
         // (one trace line for the phase; the nested NTT line precedes it, as the reference's tools expect of nested costs)
         TraceScope tr_mr(ctx, st, "MODREDUCTION");
-        for (int d = 0; d < p->dnum; d++) {
-            const size_t lo = (size_t)d * p->alpha, hi = std::min(L, lo + (size_t)p->alpha);
-            e = launch_baseconv_exact(st, ext + (size_t)d * M * N, coef + lo * N, p->up[d]->dev, N, (u32)lo, (u32)(hi - lo));
-            if (e != hipSuccess) return hip_fail(e, "launch_baseconv_exact");
+        if (p->up_batched) {
+            e = launch_baseconv_exact_jobs(st, p->up_jobs.as<BcJob>(), (u32)p->dnum, p->up_max_m, p->up_max_k, p->up[0]->dev.f64 != 0, N);
+            if (e != hipSuccess) return hip_fail(e, "launch_baseconv_exact_jobs");
+        } else {
+            for (int d = 0; d < p->dnum; d++) {
+                const size_t lo = (size_t)d * p->alpha, hi = std::min(L, lo + (size_t)p->alpha);
+                e = launch_baseconv_exact(st, ext + (size_t)d * M * N, coef + lo * N, p->up[d]->dev, N, (u32)lo, (u32)(hi - lo));
+                if (e != hipSuccess) return hip_fail(e, "launch_baseconv_exact");
+            }
         }
         TraceScope tr_ntt(ctx, st, "NTT");
         for (int path = 0; path < 2; path++) {
@@ -1066,8 +1090,9 @@ int fhe_keyswitch_apply(fhe_ctx *ctx, fhe_keyswitch *p, uint64_t *d_out0, uint64
         u64 *tP = acc + ((size_t)h * M + L) * N;
         // BGV: remove delta = t * [acc * t^-1]_P instead of [acc]_P, so that delta = 0 mod t
         if (p->plain_modulus && (rc = fhe_scalar_affine(ctx, tP, tP, p->t_inv_P.data(), nullptr, t, 1, K, L, st))) return rc;
-        if ((e = launch_baseconv_exact(st, conv + (size_t)h * L * N, tP, p->down->dev, N)) != hipSuccess) return hip_fail(e, "launch_baseconv_exact");
     }
+    e = launch_baseconv_exact_jobs(st, p->down_jobs.as<BcJob>(), 2, p->down->dev.m, p->down->dev.k, p->down->dev.f64 != 0, N);
+    if (e != hipSuccess) return hip_fail(e, "launch_baseconv_exact_jobs");
     if (p->plain_modulus && (rc = fhe_scalar_affine(ctx, conv, conv, p->t_mod_Q.data(), nullptr, t, 2, L, 0, st))) return rc;
     if ((rc = ntt_batch(ctx, conv, t, 2, L, 0, st, false))) return rc;
     for (int h = 0; h < 2; h++) {

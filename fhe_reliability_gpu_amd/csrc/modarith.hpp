@@ -32,8 +32,10 @@
 // s_load.  Host passes and the CPU emulation see a plain pointer.
 #if defined(__HIP_DEVICE_COMPILE__)
 #define FHE_GLOBAL __attribute__((address_space(1)))
+#define FHE_CONSTANT __attribute__((address_space(4)))   // read-only for the whole launch
 #else
 #define FHE_GLOBAL
+#define FHE_CONSTANT
 #endif
 #if defined(__clang__)
 #define FHE_ASSUME(x) __builtin_assume(x)

@@ -86,6 +86,13 @@ struct BaseConvPlanDev {
 // in the [M][N] layout with the digit's own limbs skipped
 hipError_t launch_baseconv_exact(hipStream_t st, u64 *out, const u64 *in, const BaseConvPlanDev &pl, u64 N, u32 gap_at = 0xFFFFFFFFu,
                                  u32 gap = 0);
+struct BcJob {
+    BaseConvPlanDev pl;
+    const u64 *in;
+    u64 *out;
+    u32 gap_at, gap;
+};
+hipError_t launch_baseconv_exact_jobs(hipStream_t st, const BcJob *dev_jobs, u32 n_jobs, int max_m, int max_k, bool f64, u64 N);
 // key-switch inner product over all digits and both key halves (aux_kernels.hip k_ks_mac)
 struct KsMacArgs {
     u64 *acc;            // [2][M][N]
