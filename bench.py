@@ -288,6 +288,26 @@ def main():
             return out
         result["also"].update(keyswitch_rates())
 
+        def abft_rate():
+            # forward transform with the weighted-checksum detector on the headline batch
+            ab = F.Abft(eng, tables)
+            flags = torch.zeros(args.polys * args.limbs, dtype=torch.int32, device="cuda")
+            call = lambda: check(lib.fhe_ntt_forward_checked(eng._h, C.c_void_p(data.data_ptr()), tables._h, ab._h, args.polys, args.limbs, 0,
+                                                             C.c_void_p(flags.data_ptr()), sptr))
+            for _ in range(3):
+                call()
+            torch.cuda.synchronize()
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record(stream)
+            for _ in range(20):
+                call()
+            e1.record(stream)
+            torch.cuda.synchronize()
+            ms = e0.elapsed_time(e1) / 20
+            return {"abft_checked_forward_same_batch": {"ms_per_step_device": ms, "overhead_vs_unchecked": ms / step_ms_dev - 1.0,
+                                                        "flags_raised": int(flags.sum().item())}}
+        result["also"].update(abft_rate())
+
     if rank == 0 and not args.no_cpu:
         from oracle import cport as O
         rp = O.root_powers(qs[0], LOGN)

@@ -627,6 +627,33 @@ __global__ void k_compare_flags(u32 *flags, const u64 *a, const u64 *b, u32 unit
     if (i < units) flags[i] = a[i] != b[i];
 }
 
+// flags[unit] = (sum of a[unit][*] mod q) != (sum of b[unit][*] mod q): per-tile partial sums of the fused checksums
+__global__ void k_compare_sums(u32 *flags, const u64 *a, u32 ta, const u64 *b, u32 tb, const LimbParams *lp, u32 limb0, u32 limbs, u32 units)
+{
+    const u32 i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < units) {
+        const u64 q = lp[limb0 + i % limbs].q;
+        u64 sa = 0, sb = 0;
+        for (u32 t = 0; t < ta; t++) {
+            sa += a[(u64)i * ta + t];      // partials are canonical (< q < 2^62)
+            sa = sa >= q ? sa - q : sa;
+        }
+        for (u32 t = 0; t < tb; t++) {
+            sb += b[(u64)i * tb + t];
+            sb = sb >= q ? sb - q : sb;
+        }
+        flags[i] = sa != sb;
+    }
+}
+
+hipError_t launch_compare_sums(hipStream_t st, u32 *flags, const u64 *a, u32 ta, const u64 *b, u32 tb, const LimbParams *lp, u32 limb0,
+                               u32 limbs, u32 units)
+{
+    if (!units) return hipSuccess;
+    hipLaunchKernelGGL(k_compare_sums, dim3((units + 255) / 256), dim3(256), 0, st, flags, a, ta, b, tb, lp, limb0, limbs, units);
+    return hipGetLastError();
+}
+
 hipError_t launch_compare_flags(hipStream_t st, u32 *flags, const u64 *a, const u64 *b, u32 units)
 {
     if (!units) return hipSuccess;

@@ -114,6 +114,8 @@ struct fhe_abft {
     fhe_ctx *ctx = nullptr;
     const fhe_ntt_tables *t = nullptr;
     DevBuf w, what, ninv;       // count x N weights (input side / output side), N^-1 per limb
+    DevBuf win, wout, wout8;    // weights for the fused checksums: twiddle-encoded (ArithU64 limbs) and, for the output side,
+                                // as residues (ArithF64 limbs); N^-1 is folded into the output-side weights
     DevBuf sum_in, sum_out;     // scratch checksums (grown on demand)
 };
 
@@ -852,6 +854,26 @@ int fhe_abft_create(fhe_ctx *ctx, const fhe_ntt_tables *t, fhe_abft **out)
     int rc = ntt_batch(ctx, a->what.as<u64>(), t, 1, t->count, 0, nullptr, false);
     if (rc) return rc;
     HIP_TRY(hipStreamSynchronize(ctx->stream));
+    {
+        // twiddle-style encodings for the checksums that ride on the transform's passes (ntt_kernels.hip k_ntt_pass_abft)
+        std::vector<u64> what((size_t)t->count * N);
+        HIP_TRY(hipMemcpy(what.data(), a->what.p, what.size() * 8, hipMemcpyDeviceToHost));
+        std::vector<Tw> ein(what.size()), eout(what.size());
+        std::vector<u64> out8(what.size());
+        for (int l = 0; l < t->count; l++) {
+            const u64 q = t->q[l];
+            for (size_t i = 0; i < N; i++) {
+                const size_t k = (size_t)l * N + i;
+                const u64 wo = host::mul_mod(what[k], ninv[l], q);
+                ein[k] = t->path[l] == PATH_F64 ? ArithF64::encode(w[k], q) : ArithU64::encode(w[k], q);
+                eout[k] = t->path[l] == PATH_F64 ? ArithF64::encode(wo, q) : ArithU64::encode(wo, q);
+                out8[k] = wo;
+            }
+        }
+        HIP_TRY(a->win.upload(ein));
+        HIP_TRY(a->wout.upload(eout));
+        HIP_TRY(a->wout8.upload(out8));
+    }
     *out = a.release();
     return FHE_OK;
 }
@@ -887,12 +909,51 @@ int fhe_ntt_forward_checked(fhe_ctx *ctx, uint64_t *d_data, const fhe_ntt_tables
     fhe_abft *m = const_cast<fhe_abft *>(a);
     HIP_TRY(hipSetDevice(ctx->device));
     hipStream_t st = pick(ctx, stream);
-    if (m->sum_in.bytes < units * 8) {
+    u32 tin = 1, tout = 1;
+    ntt_checked_tiles(t->log_n, &tin, &tout);
+    if (m->sum_in.bytes < units * 8 * tin || m->sum_out.bytes < units * 8 * tout) {
         HIP_TRY(hipStreamSynchronize(st));
-        HIP_TRY(m->sum_in.alloc(units * 16));
-        HIP_TRY(m->sum_out.alloc(units * 16));
+        HIP_TRY(m->sum_in.alloc(units * 16 * tin));
+        HIP_TRY(m->sum_out.alloc(units * 16 * tout));
     }
     int rc;
+    if (ctx->mode == 0 && ntt_checked_supported(t->log_n)) {
+        // checksums fused into the transform's passes: no extra sweep over the data
+        if ((rc = check_range(t, n_poly, limbs, start_idx))) return rc;
+        if (!units) return FHE_OK;
+        const size_t N = (size_t)1 << t->log_n;
+        const bool hook = ctx->fault_idx >= 0 && t->log_n >= 13;
+        rc = for_each_run(t, limbs, start_idx, [&](size_t off, size_t len, int path) -> int {
+            PassArgs pa{d_data + off * N, t->d_lp.as<LimbParams>(), (u32)(start_idx + off), (u32)len, (u32)(n_poly * len), (u32)limbs, nullptr};
+            u64 *si = m->sum_in.as<u64>() + off * tin, *so = m->sum_out.as<u64>() + off * tout;
+            hipError_t e;
+            if (hook) {
+                // fault-injection hook: corrupt the intermediate between the two launches (one shot, after the last run's first pass)
+                e = launch_ntt_checked(st, pa, a->win.as<Tw>(), a->wout.as<Tw>(), a->wout8.as<u64>(), si, so, t->log_n, path, 0);
+                if (e == hipSuccess && off + len == limbs) e = launch_flip_bit(st, d_data, (u64)ctx->fault_idx, ctx->fault_bit);
+                if (e != hipSuccess) return hip_fail(e, "launch_ntt_checked");
+                return FHE_OK;
+            }
+            e = launch_ntt_checked(st, pa, a->win.as<Tw>(), a->wout.as<Tw>(), a->wout8.as<u64>(), si, so, t->log_n, path);
+            return e == hipSuccess ? FHE_OK : hip_fail(e, "launch_ntt_checked");
+        });
+        if (rc) return rc;
+        if (hook) {
+            ctx->fault_idx = -1;
+            rc = for_each_run(t, limbs, start_idx, [&](size_t off, size_t len, int path) -> int {
+                PassArgs pa{d_data + off * N, t->d_lp.as<LimbParams>(), (u32)(start_idx + off), (u32)len, (u32)(n_poly * len), (u32)limbs, nullptr};
+                hipError_t e = launch_ntt_checked(st, pa, a->win.as<Tw>(), a->wout.as<Tw>(), a->wout8.as<u64>(), m->sum_in.as<u64>() + off * tin, m->sum_out.as<u64>() + off * tout,
+                                                  t->log_n, path, 1);
+                return e == hipSuccess ? FHE_OK : hip_fail(e, "launch_ntt_checked");
+            });
+            if (rc) return rc;
+        }
+        hipError_t e = launch_compare_sums(st, d_flags, m->sum_in.as<u64>(), tin, m->sum_out.as<u64>(), tout, t->d_lp.as<LimbParams>(),
+                                           (u32)start_idx, (u32)limbs, (u32)units);
+        if (e != hipSuccess) return hip_fail(e, "launch_compare_sums");
+        return FHE_OK;
+    }
+    // separate reduction launches (tiny sizes, fused-NTT mode)
     if ((rc = fhe_abft_checksum(ctx, a, 0, d_data, m->sum_in.as<u64>(), n_poly, limbs, start_idx, st))) return rc;
     if ((rc = ntt_batch(ctx, d_data, t, n_poly, limbs, start_idx, st, false))) return rc;
     if ((rc = fhe_abft_checksum(ctx, a, 1, d_data, m->sum_out.as<u64>(), n_poly, limbs, start_idx, st))) return rc;

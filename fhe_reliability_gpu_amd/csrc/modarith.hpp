@@ -194,6 +194,15 @@ struct ArithF64 {
         double r = __builtin_fma(-k, c.n, h);
         return r + l;
     }
+    // the same product with the factor given as a number: wp ~ w/q to within 2 ulp (e.g. w * ninv), |result| < 0.9 q
+    static FHE_HD elem mulmod_w(elem a, double w, double wp, const Ctx &c)
+    {
+        double h = a * w;
+        double k = __builtin_rint(a * wp);
+        double l = __builtin_fma(a, w, -h);
+        double r = __builtin_fma(-k, c.n, h);
+        return r + l;
+    }
     // Cooley-Tukey: (X, Y) -> (X + wY, X - wY)
     static FHE_HD void bfly_fwd(elem &X, elem &Y, const Tw &t, const Ctx &c)
     {
@@ -221,6 +230,12 @@ struct ArithF64 {
         const double k = __builtin_rint(a * (b * c.ninv));
         const double l = __builtin_fma(a, b, -h);
         return canonical(__builtin_fma(-k, c.n, h) + l, c);
+    }
+    // running sum of mulmod() / mulmod_w() results (each below 0.9 q in magnitude): fold back every fourth term
+    static FHE_HD void lazy_acc(elem &s, elem v, int terms, const Ctx &c)
+    {
+        s += v;
+        if ((terms & 3) == 0) reduce(s, c);
     }
     // host: encode a residue w (< q) as a twiddle
     static inline Tw encode(u64 w, u64 q)
@@ -276,6 +291,12 @@ struct ArithU64 {
         Y = mulmod(d, t, c);
     }
     static FHE_HD u64 mulvar(u64 x, u64 y, const LimbParams &p) { return barrett128(x * y, mulhi64(x, y), p.q, p.barrett_lo, p.barrett_hi); }
+    // running sum of mulmod() results (each in [0, 2q)), kept in [0, 2q)
+    static FHE_HD void lazy_acc(elem &s, elem v, int, const Ctx &c)
+    {
+        s += v;
+        s = s >= c.two_q ? s - c.two_q : s;
+    }
     static inline Tw encode(u64 w, u64 q) { return Tw{w, (u64)(((unsigned __int128)w << 64) / q)}; }
 };
 

@@ -139,6 +139,14 @@ FHE_D u64 convert_out(typename A::elem x, const typename A::Ctx &c, const Tw &in
     return A::canonical(x, c);
 }
 
+// Optional observer of a pass ("tap"): sees every element the pass reads from global memory (after the
+// conversion to the arithmetic's element type) and every final word it writes, with the element's index
+// relative to the tile base.  The ABFT detector hangs its weighted checksums here (ntt_kernels.hip), so
+// that checking a transform costs arithmetic only, not two more sweeps over the data.
+struct NoTap {
+    static constexpr bool ACTIVE = false;
+};
+
 // ---------------------------------------------------------------------------
 // Column pass: stages [S0, S0+P) of a transform of 2^LOGN points whose pair
 // distances are multiples of STRIDE = 2^(LOGN-S0-P); the tile is TC adjacent
@@ -167,9 +175,9 @@ struct ColPass {
 
     // `base` points at the first element of this tile's column 0, point 0.
     // Phase index E counts in execution order (for the inverse the field order is reversed).
-    template <int E>
+    template <int E, class TAP = NoTap>
     static FHE_D void phase(int tid, u64 *__restrict__ base, elem *__restrict__ lds, TwPtr tw, u32 hi_prefix,
-                            const typename A::Ctx &c, const Tw &inv_n)
+                            const typename A::Ctx &c, const Tw &inv_n, TAP *tap = nullptr)
     {
         constexpr int F = INVERSE ? ST::NSTEP - 1 - E : E;   // which field (forward numbering) this step handles
         constexpr int K = ST::k(F);
@@ -196,6 +204,10 @@ struct ColPass {
                     raw[r] = COHERENT_IN == 1 ? load_coherent_u64(src) : (COHERENT_IN == 2 || (STREAM && IN_MODE == IO_CANONICAL)) ? load_stream_u64(src) : *src;
                 }
                 convert_in<A, R, IN_MODE>(x, raw, c);
+                if constexpr (TAP::ACTIVE) {
+#pragma unroll
+                    for (int r = 0; r < R; r++) tap->in((g0 + ((u32)r << LOGS)) * STRIDE + col, x[r], c);
+                }
             } else {
 #pragma unroll
                 for (int r = 0; r < R; r++) x[r] = lds[lidx(g0 + ((u32)r << LOGS), col)];
@@ -270,13 +282,18 @@ struct RowPass {
         }
     }
     // coalesced copy LDS -> HBM (forward; the image already holds final 64-bit words)
-    static FHE_D void copy_out(int tid, u64 *__restrict__ base, const elem *__restrict__ lds)
+    template <class TAP = NoTap>
+    static FHE_D void copy_out(int tid, u64 *__restrict__ base, const elem *__restrict__ lds, const typename A::Ctx &c, TAP *tap = nullptr)
     {
 #pragma unroll 2
         for (int i = tid; i < TR * NPTS / 2; i += NTHREADS) {
             const u32 row = (u32)i / (NPTS / 2), g = ((u32)i % (NPTS / 2)) * 2;
             const elem *src = lds + row * ROW_LDS + row_pad(g);
             u64 *dst = base + (size_t)row * NPTS + g;
+            if constexpr (TAP::ACTIVE) {
+                tap->out(row * NPTS + g, __builtin_bit_cast(u64, src[0]), c);
+                tap->out(row * NPTS + g + 1, __builtin_bit_cast(u64, src[1]), c);
+            }
             if (STREAM && OUT_MODE == IO_CANONICAL) {
                 store_stream_u64(dst, __builtin_bit_cast(u64, src[0]));
                 store_stream_u64(dst + 1, __builtin_bit_cast(u64, src[1]));
@@ -288,14 +305,14 @@ struct RowPass {
     }
 
     // `base` = first element of the tile's first row; `row0` = index of that row in the limb.
-    template <int E>
+    template <int E, class TAP = NoTap>
     static FHE_D void phase(int tid, u64 *__restrict__ base, elem *__restrict__ lds, TwPtr tw, u32 row0,
-                            const typename A::Ctx &c, const Tw &inv_n)
+                            const typename A::Ctx &c, const Tw &inv_n, TAP *tap = nullptr)
     {
         if constexpr (STAGED && INVERSE && E == 0) {
             copy_in(tid, base, lds);
         } else if constexpr (STAGED && !INVERSE && E == ST::NSTEP) {
-            copy_out(tid, base, lds);
+            copy_out<TAP>(tid, base, lds, c, tap);
         } else {
             constexpr int SE = (STAGED && INVERSE) ? E - 1 : E;   // register-step index in execution order
             constexpr int F = INVERSE ? ST::NSTEP - 1 - SE : SE;
@@ -330,6 +347,10 @@ struct RowPass {
                         }
                     }
                     convert_in<A, R, IN_MODE>(x, raw, c);
+                    if constexpr (TAP::ACTIVE && FROM_GLOBAL) {
+#pragma unroll
+                        for (int r = 0; r < R; r++) tap->in(row * NPTS + g0 + ((u32)r << LOGS), x[r], c);
+                    }
                 } else {
 #pragma unroll
                     for (int r = 0; r < R; r++) x[r] = lrow[row_pad(g0 + ((u32)r << LOGS))];

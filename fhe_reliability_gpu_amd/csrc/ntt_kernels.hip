@@ -86,6 +86,176 @@ static hipError_t launch_size(hipStream_t st, const PassArgs &a, int logn, bool 
 }
 
 // ---------------------------------------------------------------------------
+// Checked forward transform (ABFT, rfhe_framewk/src/negaclic_ntt.py:130-149): the weighted checksums ride
+// on the passes.  The pass that reads the input accumulates sum_i w_i x_i from the registers it has just
+// loaded, the pass that writes the result accumulates sum_j w^_j X_j from the words it is about to store;
+// each workgroup stores its canonical partial sum in the unit's row of a [units][tiles] array, and the
+// comparison kernel adds the rows up modulo q (no atomics: deterministic, and no 64-bit wrap-around with 61-bit primes).
+// Weights arrive encoded like twiddles (Tw per element, arithmetic path of the limb).
+// ---------------------------------------------------------------------------
+struct AbftArgs {
+    const Tw *win;      // [table limbs][N]  input-side weights, twiddle encoding (read by ArithU64 limbs)
+    const Tw *wout;     // [table limbs][N]  output-side weights (N^-1 folded in), twiddle encoding (ArithU64 limbs)
+    const u64 *wout8;   // [table limbs][N]  output-side weights as residues (ArithF64 limbs)
+    int logp;           // log2 of the weight pattern's period (logn / 2)
+    u64 *sum_in;        // [units][tiles of the pass that reads the input], units in [poly][limb] order
+    u64 *sum_out;       // [units][tiles of the pass that writes the result]
+};
+
+template <class A, bool IN, bool OUT>
+struct ChecksumTap {
+    static constexpr bool ACTIVE = true;
+    typedef typename A::elem elem;
+    TwPtr win, wout;                   // ArithU64: Shoup-encoded weights of this limb, offset to the tile's first element
+    const u64 FHE_GLOBAL *wout8;       // ArithF64: output-side weights as plain residues (the quotient factor is one multiply)
+    u32 pos0;                          // index of the tile's first element inside its limb
+    int logp;                          // input-side weight of element i = (i mod 2^logp + 1) + (i div 2^logp + 1)
+    elem acc_in, acc_out;
+    int n_in, n_out;
+    FHE_D void in(u32 idx, elem x, const typename A::Ctx &c)
+    {
+        if constexpr (IN) {
+            if constexpr (A::PATH == PATH_F64) {
+                // generate_weights (negaclic_ntt.py:7-13) computed in place of a table read: small integers
+                const u32 i = pos0 + idx;
+                const double w = (double)((i & ((1u << logp) - 1u)) + (i >> logp) + 2u);
+                A::lazy_acc(acc_in, A::mulmod_w(x, w, w * c.ninv, c), ++n_in, c);
+            } else {
+                A::lazy_acc(acc_in, A::mulmod(x, win[idx], c), ++n_in, c);
+            }
+        }
+    }
+    FHE_D void out(u32 idx, u64 v, const typename A::Ctx &c)
+    {
+        if constexpr (OUT) {
+            if constexpr (A::PATH == PATH_F64) {
+                const double w = A::from_canonical(wout8[idx]);
+                A::lazy_acc(acc_out, A::mulmod_w(A::from_canonical(v), w, w * c.ninv, c), ++n_out, c);
+            } else {
+                A::lazy_acc(acc_out, A::mulmod(A::from_canonical(v), wout[idx], c), ++n_out, c);
+            }
+        }
+    }
+};
+
+// modular sum of one canonical value per thread over the workgroup, stored to *dst by one lane
+__device__ __forceinline__ void block_sum_mod(u64 v, u64 q, u64 *dst, u64 *red)
+{
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) {
+        v += __shfl_down(v, off, 64);
+        v = v >= q ? v - q : v;
+    }
+    const int wave = threadIdx.x >> 6;
+    if ((threadIdx.x & 63) == 0) red[wave] = v;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        u64 s = 0;
+        for (int w = 0; w < NTT_THREADS / 64; w++) {
+            s += red[w];
+            s = s >= q ? s - q : s;
+        }
+        *dst = s;
+    }
+}
+
+template <class PASS, int LOGN, bool IS_COL, bool IN, bool OUT>
+__global__ __launch_bounds__(NTT_THREADS) void k_ntt_pass_abft(PassArgs a, AbftArgs ab)
+{
+    typedef typename PASS::Arith A;
+    __shared__ __attribute__((aligned(16))) typename PASS::elem lds[PASS::LDS_ELEMS > 0 ? PASS::LDS_ELEMS : 1];
+    __shared__ u64 red[2][NTT_THREADS / 64];
+    u32 limb, row0 = 0;
+    u64 *base;
+    if constexpr (IS_COL) base = col_tile<PASS, LOGN>(blockIdx.x, a, limb);
+    else base = row_tile<PASS, LOGN>(blockIdx.x, a, limb, row0);
+    // position of the tile inside its limb and index of the unit in [poly][limb] order
+    const u32 unit = blockIdx.x / PASS::TILES, polys = a.units / a.limbs;
+    const u32 l = unit / polys, poly = unit % polys, slot = poly * a.poly_stride + l;
+    const u32 pos0 = (u32)((base - a.data) & (((size_t)1 << LOGN) - 1));
+    const LimbParams &p = a.lp[limb];
+    const typename A::Ctx ctx = A::make_ctx(p);
+    const TwPtr tw = as_global(p.fwd);
+    const Tw inv_n = p.inv_n;
+    const int tid = threadIdx.x;
+    ChecksumTap<A, IN, OUT> tap{as_global(ab.win) + ((size_t)limb << LOGN) + pos0, as_global(ab.wout) + ((size_t)limb << LOGN) + pos0,
+                                (const u64 FHE_GLOBAL *)ab.wout8 + ((size_t)limb << LOGN) + pos0, pos0, ab.logp,
+                                typename A::elem(0), typename A::elem(0), 0, 0};
+    PASS::template phase<0>(tid, base, lds, tw, row0, ctx, inv_n, &tap);
+    if constexpr (PASS::NPHASE > 1) {
+        __syncthreads();
+        PASS::template phase<1>(tid, base, lds, tw, row0, ctx, inv_n, &tap);
+    }
+    if constexpr (PASS::NPHASE > 2) {
+        __syncthreads();
+        PASS::template phase<2>(tid, base, lds, tw, row0, ctx, inv_n, &tap);
+    }
+    if constexpr (PASS::NPHASE > 3) {
+        __syncthreads();
+        PASS::template phase<3>(tid, base, lds, tw, row0, ctx, inv_n, &tap);
+    }
+    const u32 tile = blockIdx.x % PASS::TILES;
+    if constexpr (IN) block_sum_mod(A::canonical(tap.acc_in, ctx), p.q, ab.sum_in + (size_t)slot * PASS::TILES + tile, red[0]);
+    if constexpr (OUT) block_sum_mod(A::canonical(tap.acc_out, ctx), p.q, ab.sum_out + (size_t)slot * PASS::TILES + tile, red[1]);
+}
+
+template <class A, int LOGN>
+static hipError_t launch_checked(hipStream_t st, const PassArgs &a, const AbftArgs &ab, int which)
+{
+    constexpr int GEO = LOGN >= 13 ? 1 : 0;
+    typedef Passes<A, LOGN, false, GEO> PS;
+    if constexpr (!PS::G::TWO_PASS) {
+        if (which == 1) return hipSuccess;
+        hipLaunchKernelGGL((k_ntt_pass_abft<typename PS::Single, LOGN, false, true, true>), dim3(a.units * PS::Single::TILES), dim3(NTT_THREADS), 0, st, a, ab);
+    } else {
+        if (which != 1) hipLaunchKernelGGL((k_ntt_pass_abft<typename PS::Col, LOGN, true, true, false>), dim3(a.units * PS::Col::TILES), dim3(NTT_THREADS), 0, st, a, ab);
+        if (which != 0) hipLaunchKernelGGL((k_ntt_pass_abft<typename PS::Row, LOGN, false, false, true>), dim3(a.units * PS::Row::TILES), dim3(NTT_THREADS), 0, st, a, ab);
+    }
+    return hipGetLastError();
+}
+
+bool ntt_checked_supported(int logn) { return logn >= 5 && logn <= NTT_MAX_LOGN; }
+
+template <int LOGN> static void checked_tiles_t(u32 *tin, u32 *tout)
+{
+    typedef Passes<ArithF64, LOGN, false, (LOGN >= 13 ? 1 : 0)> PS;
+    if constexpr (!PS::G::TWO_PASS) *tin = *tout = PS::Single::TILES;
+    else {
+        *tin = PS::Col::TILES;
+        *tout = PS::Row::TILES;
+    }
+}
+// partial sums per unit on the input / output side (row lengths of sum_in / sum_out)
+void ntt_checked_tiles(int logn, u32 *tin, u32 *tout)
+{
+    *tin = *tout = 1;
+    switch (logn) {
+#define FHE_CASE(L) case L: checked_tiles_t<L>(tin, tout); break;
+        FHE_CASE(5) FHE_CASE(6) FHE_CASE(7) FHE_CASE(8) FHE_CASE(9) FHE_CASE(10) FHE_CASE(11) FHE_CASE(12) FHE_CASE(13)
+        FHE_CASE(14) FHE_CASE(15) FHE_CASE(16) FHE_CASE(17) FHE_CASE(18) FHE_CASE(19) FHE_CASE(20)
+#undef FHE_CASE
+    default: break;
+    }
+}
+
+// forward transform with the checksums fused in; which as in launch_ntt (the fault hook splits the launches)
+hipError_t launch_ntt_checked(hipStream_t st, const PassArgs &a, const Tw *win, const Tw *wout, const u64 *wout8, u64 *sum_in, u64 *sum_out,
+                              int logn, int path, int which)
+{
+    if (a.units == 0) return hipSuccess;
+    if (a.map) return hipErrorInvalidValue;
+    const AbftArgs ab{win, wout, wout8, logn / 2, sum_in, sum_out};
+    switch (logn) {
+#define FHE_CASE(L) \
+    case L: return path == PATH_F64 ? launch_checked<ArithF64, L>(st, a, ab, which) : launch_checked<ArithU64, L>(st, a, ab, which);
+        FHE_CASE(5) FHE_CASE(6) FHE_CASE(7) FHE_CASE(8) FHE_CASE(9) FHE_CASE(10) FHE_CASE(11) FHE_CASE(12) FHE_CASE(13)
+        FHE_CASE(14) FHE_CASE(15) FHE_CASE(16) FHE_CASE(17) FHE_CASE(18) FHE_CASE(19) FHE_CASE(20)
+#undef FHE_CASE
+    default: return hipErrorInvalidValue;
+    }
+}
+
+// ---------------------------------------------------------------------------
 // Negacyclic product, middle launch: for one row tile, finish the forward transform of a and of b
 // (row pass), multiply, and run the first inverse pass (the row pass again), reading each input tile
 // once and writing the product tile once.  The forward row pass leaves final words in the LDS image

@@ -16,6 +16,15 @@ hipError_t launch_ntt(hipStream_t st, const PassArgs &a, int logn, bool inverse,
 bool polymul_fused_supported(int logn);
 hipError_t launch_polymul(hipStream_t st, const PassArgs &a, u64 *b, u64 *c, int logn, int path);
 
+// forward transform with the ABFT checksums fused into the passes (ntt_kernels.hip): sum_in / sum_out are
+// [units][tin] / [units][tout] partial sums (units in [poly][limb] order; tin, tout from ntt_checked_tiles);
+// win / wout = [table limbs][N] weights in twiddle encoding (used by ArithU64 limbs), wout8 = output-side weights as
+// residues (ArithF64 limbs; their input-side weights are computed in place).  `which` as in launch_ntt.
+bool ntt_checked_supported(int logn);
+void ntt_checked_tiles(int logn, u32 *tin, u32 *tout);
+hipError_t launch_ntt_checked(hipStream_t st, const PassArgs &a, const Tw *win, const Tw *wout, const u64 *wout8, u64 *sum_in, u64 *sum_out,
+                              int logn, int path, int which = -1);
+
 // ---- ntt_fused.hip: single-launch variant for two-pass sizes --------------------
 bool fused_supported(int logn);
 size_t fused_ctl_bytes(u32 units);
@@ -64,6 +73,9 @@ hipError_t launch_weighted_checksum(hipStream_t st, u64 *out, const u64 *x, cons
                                     u32 limb0, u32 limbs, u32 units, u32 poly_stride, int logn);
 // flags[unit] = a[unit] != b[unit]
 hipError_t launch_compare_flags(hipStream_t st, u32 *flags, const u64 *a, const u64 *b, u32 units);
+// flags[unit] = (sum of a[unit][0..ta) mod q_l) != (sum of b[unit][0..tb) mod q_l)  (unit = poly * limbs + l)
+hipError_t launch_compare_sums(hipStream_t st, u32 *flags, const u64 *a, u32 ta, const u64 *b, u32 tb, const LimbParams *lp, u32 limb0,
+                               u32 limbs, u32 units);
 // Galois automorphism x -> x^k: coefficient domain (sign-aware scatter) and NTT domain (gather)
 hipError_t launch_automorphism(hipStream_t st, u64 *dst, const u64 *src, const LimbParams *lp, u32 limb0, u32 limbs, u32 units,
                                int logn, u32 k);

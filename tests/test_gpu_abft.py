@@ -78,3 +78,42 @@ def test_detector_flags_only_the_limb_hit_in_flight(F, eng, bits):
     faulty[1, 2, 77] ^= np.uint64(1 << 5)
     d = eng.upload(faulty)
     assert not ab.forward_checked(d, n_poly=polys).any()
+
+
+@pytest.mark.parametrize("logn", [4, 5, 8, 11, 12, 13, 15, 16, 17])
+def test_checked_transform_every_plan_shape(F, eng, logn):
+    """The checksums ride on the transform's passes (2^5 and up; tiny sizes use separate reductions): same output
+    as the unchecked transform, no flag on a clean run, mixed arithmetic paths and a limb window in one call."""
+    from oracle import cport as O
+    N = 1 << logn
+    qs = F.create_moduli(N, [50, 61, 61, 50])
+    t = eng.tables(logn, qs)
+    ab = F.Abft(eng, t)
+    rng = np.random.default_rng(logn)
+    start, limbs, polys = 1, 3, 2
+    data = np.stack([np.stack([rng.integers(0, q, N, dtype=np.uint64) for q in qs[start:start + limbs]]) for _ in range(polys)])
+    data[1, 0, 3] = np.uint64(2**64 - 5)                      # an out-of-range word: reduced modulo its prime on both sides
+    d = eng.upload(data)
+    flags = ab.forward_checked(d, n_poly=polys, limbs=limbs, start=start)
+    assert not flags.any()
+    got = d.download()
+    for p in range(polys):
+        for l in range(limbs):
+            q = qs[start + l]
+            assert (got[p, l] == O.nwt_forward(data[p, l] % np.uint64(q), q, O.root_powers(q, logn))).all()
+
+
+def test_checked_transform_fault_at_full_size(F, eng):
+    # N = 2^16: a flip between the column pass and the row pass of one limb-polynomial out of 6
+    from fhe_reliability_gpu_amd._lib import check, lib
+    logn, N, limbs, polys = 16, 1 << 16, 2, 3
+    qs = F.create_moduli(N, [50, 61])
+    t = eng.tables(logn, qs)
+    ab = F.Abft(eng, t)
+    rng = np.random.default_rng(5)
+    data = np.stack([np.stack([rng.integers(0, q, N, dtype=np.uint64) for q in qs]) for _ in range(polys)])
+    for unit in (0, 3, 5):
+        d = eng.upload(data)
+        check(lib.fhe_ctx_inject_fault(eng._h, unit * N + 4242, 11))
+        flags = ab.forward_checked(d, n_poly=polys)
+        assert flags.tolist() == [1 if u == unit else 0 for u in range(polys * limbs)]
