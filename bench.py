@@ -308,6 +308,26 @@ def main():
                                                         "flags_raised": int(flags.sum().item())}}
         result["also"].update(abft_rate())
 
+        def pcie_inclusive():
+            # the boundary can hand over HOST buffers (ntt_test does): pinned host -> device, transform, device -> host
+            host = torch.empty((args.polys, args.limbs, N), dtype=torch.int64).pin_memory()
+            host.copy_(pristine.cpu())
+            def call():
+                with torch.cuda.stream(stream):
+                    data.copy_(host, non_blocking=True)
+                    step()
+                    host.copy_(data, non_blocking=True)
+            call()
+            torch.cuda.synchronize()
+            t = time.perf_counter()
+            for _ in range(5):
+                call()
+            torch.cuda.synchronize()
+            dt = (time.perf_counter() - t) / 5
+            return {"pcie_inclusive_same_batch (pinned host in, host out; not the headline)": {
+                "ms_per_step_wall": dt * 1e3, "ntt_per_s": units / dt, "GBps_each_way": args.polys * args.limbs * N * 8 / (dt / 2) / 1e9}}
+        result["also"].update(pcie_inclusive())
+
     if rank == 0 and not args.no_cpu:
         from oracle import cport as O
         rp = O.root_powers(qs[0], LOGN)
