@@ -208,7 +208,8 @@ int fhe_automorphism_ntt(fhe_ctx *ctx, uint64_t *d_dst, const uint64_t *d_src, i
  * `t` holds L ciphertext primes followed by K special primes; the L primes are cut into `dnum` digits of
  * ceil(L/dnum) consecutive limbs (SEAL: dnum = L, one prime per digit; draw_dnum_rot_mul.py:64 sweeps dnum).
  *   d_c   : L x N, NTT domain                       d_evk : dnum x 2 x (L+K) x N, NTT domain (b_d, a_d)
- *   d_out0, d_out1 : L x N, NTT domain; out0 + out1*s ~ c*s' when evk encrypts P*Qhat_d*[Qhat_d^-1]_{Q_d}*s'. */
+ *   d_out0, d_out1 : L x N, NTT domain; out0 + out1*s ~ c*s' when evk encrypts P*Qhat_d*[Qhat_d^-1]_{Q_d}*s'.
+ * The plan owns the intermediate buffers (extended digits, accumulators): one call at a time per plan. */
 int fhe_keyswitch_create(fhe_ctx *ctx, const fhe_ntt_tables *t, int L, int K, int dnum, fhe_keyswitch **out);
 /* BGV form of the mod-down: with plaintext modulus `plain_modulus` (0 = off, the CKKS-style flooring
  * above) the removed part delta satisfies delta = acc mod P and delta = 0 mod plain_modulus, so the
@@ -247,7 +248,9 @@ int fhe_abft_checksum(fhe_ctx *ctx, const fhe_abft *a, int side, const uint64_t 
                       size_t limbs, size_t start_idx, void *stream);
 /* Forward NTT with the detector around it: d_flags[unit] (uint32) = 1 where the two checksums differ,
  * i.e. where a fault hit the transform of that limb-polynomial (faults already present in the input
- * are, by construction, not flagged). */
+ * are, by construction, not flagged).  For N >= 32 the two checksums are accumulated inside the
+ * transform's own passes (from the registers just loaded / the words about to be stored): no extra
+ * sweep over the data.  The detector object owns scratch: one call at a time per fhe_abft. */
 int fhe_ntt_forward_checked(fhe_ctx *ctx, uint64_t *d_data, const fhe_ntt_tables *t, const fhe_abft *a, size_t n_poly,
                             size_t limbs, size_t start_idx, uint32_t *d_flags, void *stream);
 /* Test hook for the detector: XOR bit `bit` of word `idx` of the buffer BETWEEN the two launches of the

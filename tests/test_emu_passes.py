@@ -19,11 +19,14 @@ p64 = C.POINTER(C.c_uint64)
 
 @pytest.fixture(scope="module")
 def emu():
-    so = os.path.join(EMU_DIR, "libemu_ntt.so")
+    # FHE_EMU_SANITIZE=1 (with LD_PRELOAD=$(gcc -print-file-name=libasan.so)): AddressSanitizer + UBSan build of the
+    # emulation -- the CPU-side sanitizer run of the kernels' indexing (GPU sanitizers are not available on the pool)
+    san = os.environ.get("FHE_EMU_SANITIZE") == "1"
+    so = os.path.join(EMU_DIR, "libemu_ntt_san.so" if san else "libemu_ntt.so")
     srcs = [os.path.join(EMU_DIR, "emu_ntt.cpp")] + [os.path.join(CSRC, f) for f in ("modarith.hpp", "ntt_core.hpp", "ntt_plan.hpp", "ntt_fused.hpp")]
     if not os.path.exists(so) or os.path.getmtime(so) < max(os.path.getmtime(s) for s in srcs):
-        subprocess.check_call(["g++", "-O2", "-std=c++17", "-ffp-contract=off", "-shared", "-fPIC", "-I" + CSRC,
-                               srcs[0], "-o", so])
+        flags = ["-O1", "-g", "-fsanitize=address,undefined", "-fno-sanitize-recover=undefined", "-fno-omit-frame-pointer"] if san else ["-O2"]
+        subprocess.check_call(["g++"] + flags + ["-std=c++17", "-ffp-contract=off", "-shared", "-fPIC", "-I" + CSRC, srcs[0], "-o", so])
     L = C.CDLL(so)
     L.emu_ntt.restype = C.c_int
     L.emu_ntt.argtypes = [p64, C.c_int, C.c_int, C.c_int, C.c_int, p64, p64, C.c_int, C.c_int]
