@@ -540,6 +540,7 @@ int fhe_ntt_tables_create(fhe_ctx *ctx, int log_n, const uint64_t *q, int count,
     const size_t N = (size_t)1 << log_n;
     std::vector<u64> rows((size_t)count * N), psi(count);
     for (int l = 0; l < count; l++) {
+        if (q[l] < 2 || q[l] >= ((u64)1 << 61)) return fail(FHE_ERR_UNSUPPORTED, "modulus " + std::to_string(q[l]) + " outside [2, 2^61)");
         if (!host::min_primitive_root(q[l], (u64)2 * N, psi[l]))
             return fail(FHE_ERR_INVALID, "modulus " + std::to_string(q[l]) + " has no primitive 2N-th root");
         host::root_powers(q[l], log_n, psi[l], rows.data() + (size_t)l * N);

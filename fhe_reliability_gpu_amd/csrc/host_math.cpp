@@ -108,9 +108,12 @@ void const_ratio(u64 q, u64 out[3])
 bool min_primitive_root(u64 q, u64 order, u64 &root)
 {
     if (order < 2 || (order & (order - 1)) || (q - 1) % order) return false;
-    // any element whose (order/2)-th power is -1 after raising to (q-1)/order
+    // any element whose (order/2)-th power is -1 after raising to (q-1)/order.  For a prime q every second
+    // candidate works, so the search is bounded: a modulus that yields nothing in 4096 tries is not a prime
+    // with a subgroup of that order (the unbounded loop would run for 2^60 steps on a composite modulus).
     u64 g = 0;
-    for (u64 c = 2; c < q && !g; c++) {
+    const u64 last = q - 1 < 4098 ? q - 1 : 4098;
+    for (u64 c = 2; c <= last && !g; c++) {
         u64 r = pow_mod(c, (q - 1) / order, q);
         if (pow_mod(r, order / 2, q) == q - 1) g = r;
     }

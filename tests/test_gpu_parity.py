@@ -533,3 +533,59 @@ def test_naive_gemm_test_cli():
     r = _run_cli("naive_gemm_test")
     assert r.returncode == 0, r.stderr
     assert "MISMATCH" not in r.stdout
+
+
+# ------------------------------------------------------------------ edges: empty, limits, error status
+def test_empty_batches_are_no_ops(F, eng):
+    from fhe_reliability_gpu_amd._lib import lib
+    logn, N = 12, 4096
+    qs = F.create_moduli(N, [50, 50])
+    t = eng.tables(logn, qs)
+    data = np.arange(2 * N, dtype=np.uint64).reshape(1, 2, N) % np.uint64(qs[0])
+    d = eng.upload(data)
+    for fn in (lib.fhe_ntt_forward_batch, lib.fhe_ntt_inverse_batch):
+        assert fn(eng._h, d.ptr, t._h, 0, 2, 0, None) == 0            # no polynomials
+        assert fn(eng._h, d.ptr, t._h, 1, 0, 0, None) == 0            # no limbs
+    assert lib.fhe_modmul(eng._h, d.ptr, d.ptr, d.ptr, t._h, 0, 2, 0, None) == 0
+    assert lib.fhe_polymul(eng._h, d.ptr, d.ptr, d.ptr, t._h, 0, 2, 0, None) == 0
+    eng.check()
+    assert (d.download() == data).all()
+
+
+def test_error_status_instead_of_launch(F, eng):
+    """Every entry point reports bad shapes through its status (and fhe_last_error), never through a fault."""
+    from fhe_reliability_gpu_amd._lib import lib
+    logn, N = 10, 1024
+    qs = F.create_moduli(N, [50, 50])
+    t = eng.tables(logn, qs)
+    d = eng.upload(np.zeros((1, 2, N), dtype=np.uint64))
+    assert lib.fhe_ntt_forward_batch(eng._h, d.ptr, t._h, 1, 3, 0, None) == 1        # more limbs than the table set has
+    assert lib.fhe_ntt_forward_batch(eng._h, d.ptr, t._h, 1, 2, 1, None) == 1        # window runs past the last limb
+    assert lib.fhe_ntt_forward_batch(eng._h, None, t._h, 1, 2, 0, None) == 1         # null data
+    assert b"" != lib.fhe_last_error()
+    with pytest.raises(F.FheError):
+        eng.tables(21, [qs[0]])                                                      # beyond 2^20
+    with pytest.raises(F.FheError):
+        eng.tables(logn, [(1 << 62) + 1])                                            # modulus too wide for the integer path
+    with pytest.raises(F.FheError):
+        F.BaseConv(eng, [15, 21], [qs[0]])                                           # input moduli not coprime
+    with pytest.raises(F.FheError):
+        F.KeySwitch(eng, t, 2, 1, 1)                                                 # L + K exceeds the table set
+    eng.check()
+
+
+@pytest.mark.parametrize("logn", [19, 20])
+def test_largest_sizes(F, eng, O, logn):
+    # the upper end of the plan table (2^20: 8 MiB per limb); one limb per arithmetic path, forward + inverse
+    N = 1 << logn
+    qs = F.create_moduli(N, [50, 61])
+    t = eng.tables(logn, qs)
+    rng = np.random.default_rng(logn)
+    data = _rand_limbs(rng, qs, N, 1)
+    d = eng.upload(data)
+    t.forward(d)
+    fwd = d.download()
+    for l, q in enumerate(qs):
+        assert (fwd[0, l] == O.nwt_forward(data[0, l], q, O.root_powers(q, logn))).all()
+    t.inverse(d)
+    assert (d.download() == data).all()
