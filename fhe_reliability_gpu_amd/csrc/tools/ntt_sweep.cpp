@@ -59,7 +59,16 @@ int main(int argc, char **argv)
             for (int wgs : {256, 384, 512, 768}) cfgs.push_back({1, dist, wgs, nt});
     if (const char *e = getenv("SWEEP_WGS")) {
         cfgs.resize(2);
-        for (int nt : {2, 3, 4, 5, 6, 7})
+        std::vector<int> variants = {2, 3, 4, 5, 6, 7};
+        if (const char *v = getenv("SWEEP_VARIANTS")) {          // comma-separated fused_variant values
+            variants.clear();
+            for (const char *p = v; *p;) {
+                variants.push_back(atoi(p));
+                while (*p && *p != ',') p++;
+                if (*p) p++;
+            }
+        }
+        for (int nt : variants)
             for (int dist : {getenv("SWEEP_DIST") ? atoi(getenv("SWEEP_DIST")) : 3}) cfgs.push_back({1, dist, atoi(e), nt});
     }
     const double alg_bytes = 16.0 * N * limbs * polys;
