@@ -485,27 +485,36 @@ hipError_t launch_crt_garner(hipStream_t st, u64 *x_lo, u64 *x_hi, const u64 *re
 // ---------------------------------------------------------------------------
 // out = (a - b) * s_l mod q_l per limb: the mod-down tail (subtract the converted special-prime part,
 // multiply by P^-1)
-__global__ __launch_bounds__(256) void k_sub_scale(u64 *out, const u64 *a, const u64 *b, const u64 *scal, const LimbParams *lp,
-                                                   u32 limb0, u32 limbs, int logn)
+// Last step of the key-switch mod-down for both halves in one launch (blockIdx.y = half):
+//   out_h = (a_h - b_h) * scal[l] (+ add_h) mod q_l,   a_h = a + h * a_stride, b_h = b + h * b_stride
+// `add0` (half 0 only) lets a rotation fold its sigma(c0) term in instead of a separate add and copy.
+__global__ __launch_bounds__(256) void k_sub_scale(SubScaleArgs p)
 {
-    const u64 total = (u64)limbs << logn;
+    const u32 h = blockIdx.y;
+    u64 *out = h ? p.out1 : p.out0;
+    const u64 *a = p.a + (u64)h * p.a_stride, *b = p.b + (u64)h * p.b_stride, *add = h ? nullptr : p.add0;
+    const u64 total = (u64)p.limbs << p.logn;
     for (u64 i = blockIdx.x * (u64)blockDim.x + threadIdx.x; i < total; i += (u64)gridDim.x * blockDim.x) {
-        const u32 l = (u32)(i >> logn);
-        const LimbParams &p = lp[limb0 + l];
-        const u64 q = p.q, r0 = p.barrett_lo, r1 = p.barrett_hi;
+        const u32 l = (u32)(i >> p.logn);
+        const LimbParams &lp = p.lp[p.limb0 + l];
+        const u64 q = lp.q, r0 = lp.barrett_lo, r1 = lp.barrett_hi;
         const u64 x = barrett128(a[i], 0, q, r0, r1), y = barrett128(b[i], 0, q, r0, r1);
         const u64 d = x >= y ? x - y : x + q - y;
-        out[i] = mulmod_b(d, scal[l], q, r0, r1);
+        u64 v = mulmod_b(d, p.scal[l], q, r0, r1);
+        if (add) {
+            v += barrett128(add[i], 0, q, r0, r1);
+            v = v >= q ? v - q : v;
+        }
+        out[i] = v;
     }
 }
 
-hipError_t launch_sub_scale(hipStream_t st, u64 *out, const u64 *a, const u64 *b, const u64 *scal, const LimbParams *lp, u32 limb0,
-                            u32 limbs, int logn)
+hipError_t launch_sub_scale(hipStream_t st, const SubScaleArgs &p)
 {
-    const u64 total = (u64)limbs << logn;
+    const u64 total = (u64)p.limbs << p.logn;
     if (!total) return hipSuccess;
     u64 want = (total + 255) / 256;
-    hipLaunchKernelGGL(k_sub_scale, dim3((u32)(want > 8192 ? 8192 : want)), dim3(256), 0, st, out, a, b, scal, lp, limb0, limbs, logn);
+    hipLaunchKernelGGL(k_sub_scale, dim3((u32)(want > 8192 ? 8192 : want), p.out1 ? 2 : 1), dim3(256), 0, st, p);
     return hipGetLastError();
 }
 
@@ -691,8 +700,12 @@ hipError_t launch_automorphism(hipStream_t st, u64 *dst, const u64 *src, const L
 
 // The same map on NTT-domain limbs (bit-reversed order): slot j evaluates at psi^(2 bitrev(j) + 1), and
 // (sigma_k f)(x) = f(x^k), so dst[j] = src[j'] with 2 bitrev(j') + 1 = (2 bitrev(j) + 1) k mod 2N.
-__global__ __launch_bounds__(256) void k_automorphism_ntt(u64 *dst, const u64 *src, u32 units, int logn, u32 k)
+__global__ __launch_bounds__(256) void k_automorphism_ntt(u64 *dst, const u64 *src, u64 *dst_b, const u64 *src_b, u32 units, int logn, u32 k)
 {
+    if (blockIdx.y) {          // second (source, destination) pair of the same shape: both parts of a ciphertext in one launch
+        dst = dst_b;
+        src = src_b;
+    }
     const u64 total = (u64)units << logn;
     const u32 n = 1u << logn, mask2 = 2 * n - 1;
     for (u64 g = blockIdx.x * (u64)blockDim.x + threadIdx.x; g < total; g += (u64)gridDim.x * blockDim.x) {
@@ -704,12 +717,13 @@ __global__ __launch_bounds__(256) void k_automorphism_ntt(u64 *dst, const u64 *s
     }
 }
 
-hipError_t launch_automorphism_ntt(hipStream_t st, u64 *dst, const u64 *src, u32 units, int logn, u32 k)
+hipError_t launch_automorphism_ntt(hipStream_t st, u64 *dst, const u64 *src, u32 units, int logn, u32 k, u64 *dst_b, const u64 *src_b)
 {
     const u64 total = (u64)units << logn;
     if (!total) return hipSuccess;
     u64 want = (total + 255) / 256;
-    hipLaunchKernelGGL(k_automorphism_ntt, dim3((u32)(want > 8192 ? 8192 : want)), dim3(256), 0, st, dst, src, units, logn, k);
+    hipLaunchKernelGGL(k_automorphism_ntt, dim3((u32)(want > 8192 ? 8192 : want), dst_b ? 2 : 1), dim3(256), 0, st, dst, src, dst_b, src_b, units,
+                       logn, k);
     return hipGetLastError();
 }
 

@@ -1092,8 +1092,18 @@ int fhe_keyswitch_destroy(fhe_keyswitch *p)
 // with the launches batched: one INTT, one base extension per digit written straight into the [dnum][M][N]
 // layout, ONE forward transform over every extended limb of every digit (unit list), ONE inner-product launch
 // for all digits and both key halves, and a mod-down that handles both halves per launch where the layout allows.
+static int keyswitch_core(fhe_ctx *ctx, fhe_keyswitch *p, uint64_t *d_out0, uint64_t *d_out1, const uint64_t *d_c, const uint64_t *d_evk,
+                          const uint64_t *d_add0, void *stream);
+
 int fhe_keyswitch_apply(fhe_ctx *ctx, fhe_keyswitch *p, uint64_t *d_out0, uint64_t *d_out1, const uint64_t *d_c,
                         const uint64_t *d_evk, void *stream)
+{
+    return keyswitch_core(ctx, p, d_out0, d_out1, d_c, d_evk, nullptr, stream);
+}
+
+// d_add0 (optional, L x N): added to the first output part -- a rotation passes sigma(c0) here
+static int keyswitch_core(fhe_ctx *ctx, fhe_keyswitch *p, uint64_t *d_out0, uint64_t *d_out1, const uint64_t *d_c, const uint64_t *d_evk,
+                          const uint64_t *d_add0, void *stream)
 {
     if (!ctx || !p || !d_out0 || !d_out1 || !d_c || !d_evk) return fail(FHE_ERR_INVALID, "null argument");
     HIP_TRY(hipSetDevice(ctx->device));
@@ -1147,7 +1157,6 @@ int fhe_keyswitch_apply(fhe_ctx *ctx, fhe_keyswitch *p, uint64_t *d_out0, uint64
         });
         if (rc) return rc;
     }
-    u64 *outs[2] = {d_out0, d_out1};
     for (int h = 0; h < 2; h++) {
         u64 *tP = acc + ((size_t)h * M + L) * N;
         // BGV: remove delta = t * [acc * t^-1]_P instead of [acc]_P, so that delta = 0 mod t
@@ -1157,10 +1166,8 @@ int fhe_keyswitch_apply(fhe_ctx *ctx, fhe_keyswitch *p, uint64_t *d_out0, uint64
     if (e != hipSuccess) return hip_fail(e, "launch_baseconv_exact_jobs");
     if (p->plain_modulus && (rc = fhe_scalar_affine(ctx, conv, conv, p->t_mod_Q.data(), nullptr, t, 2, L, 0, st))) return rc;
     if ((rc = ntt_batch(ctx, conv, t, 2, L, 0, st, false))) return rc;
-    for (int h = 0; h < 2; h++) {
-        e = launch_sub_scale(st, outs[h], acc + (size_t)h * M * N, conv + (size_t)h * L * N, p->pinv.as<u64>(), lp, 0, (u32)L, p->log_n);
-        if (e != hipSuccess) return hip_fail(e, "launch_sub_scale");
-    }
+    const SubScaleArgs sa{d_out0, d_out1, acc, conv, d_add0, p->pinv.as<u64>(), (u64)(M * N), (u64)(L * N), lp, 0u, (u32)L, p->log_n};
+    if ((e = launch_sub_scale(st, sa)) != hipSuccess) return hip_fail(e, "launch_sub_scale");
     return FHE_OK;
 }
 
@@ -1173,16 +1180,13 @@ int fhe_rotate(fhe_ctx *ctx, fhe_keyswitch *p, uint64_t *d_out0, uint64_t *d_out
     hipStream_t st = pick(ctx, stream);
     TraceScope tr(ctx, st, "ROTATE", true);
     const size_t L = p->L, N = (size_t)1 << p->log_n;
-    u64 *sig1 = p->rot.as<u64>(), *k0 = sig1 + L * N, *k1 = k0 + L * N;
-    int rc;
-    // sigma on both parts: in the NTT domain a permutation of the slots
-    if ((rc = fhe_automorphism_ntt(ctx, d_out0, d_c0, p->log_n, galois_elt, L, st))) return rc;
-    if ((rc = fhe_automorphism_ntt(ctx, sig1, d_c1, p->log_n, galois_elt, L, st))) return rc;
-    // sigma(c1) is a ciphertext part under sigma(s): switch it back to s with the Galois key
-    if ((rc = fhe_keyswitch_apply(ctx, p, k0, k1, sig1, d_galois_key, st))) return rc;
-    if ((rc = fhe_modadd(ctx, d_out0, d_out0, k0, p->t, 1, L, 0, st))) return rc;
-    HIP_TRY(hipMemcpyAsync(d_out1, k1, L * N * 8, hipMemcpyDeviceToDevice, st));
-    return FHE_OK;
+    u64 *sig0 = p->rot.as<u64>(), *sig1 = sig0 + L * N;
+    // sigma on both parts (in the NTT domain a permutation of the slots), one launch
+    hipError_t e = launch_automorphism_ntt(st, sig0, d_c0, (u32)L, p->log_n, galois_elt, sig1, d_c1);
+    if (e != hipSuccess) return hip_fail(e, "launch_automorphism_ntt");
+    // sigma(c1) is a ciphertext part under sigma(s): switch it back to s with the Galois key; the mod-down's last
+    // launch adds sigma(c0) to the first part and writes both parts where the caller wants them
+    return keyswitch_core(ctx, p, d_out0, d_out1, sig1, d_galois_key, sig0, st);
 }
 
 int fhe_ctx_trace(fhe_ctx *ctx, int enable)

@@ -64,9 +64,17 @@ hipError_t launch_bitrev_scale(hipStream_t st, u64 *dst, const u64 *src, int log
 hipError_t launch_fourstep_mid(hipStream_t st, u64 *out, const u64 *in, u32 rows, u32 cols, int log_cols,
                                const u64 *tw, const ModConst &mc, bool with_twiddle);
 hipError_t launch_transpose(hipStream_t st, u64 *out, const u64 *in, u32 rows, u32 cols);
-// out = (a - b) * scal[l] mod q_l over `limbs` limbs starting at table index limb0
-hipError_t launch_sub_scale(hipStream_t st, u64 *out, const u64 *a, const u64 *b, const u64 *scal, const LimbParams *lp, u32 limb0,
-                            u32 limbs, int logn);
+// out_h = (a_h - b_h) * scal[l] (+ add0 for h = 0) mod q_l over `limbs` limbs from table index limb0, for one half
+// (out1 == nullptr) or both halves of a key switch in one launch; a_h = a + h * a_stride, b_h = b + h * b_stride (in words)
+struct SubScaleArgs {
+    u64 *out0, *out1;
+    const u64 *a, *b, *add0, *scal;
+    u64 a_stride, b_stride;
+    const LimbParams *lp;
+    u32 limb0, limbs;
+    int logn;
+};
+hipError_t launch_sub_scale(hipStream_t st, const SubScaleArgs &p);
 // out[unit] = sum_i w[limb][i] * x[unit][i] mod q_limb (one workgroup per limb-polynomial): the weighted
 // checksum of the reference's ECC (rfhe_framewk/src/negaclic_ntt.py:130-149); scal[limb] multiplies the sum
 hipError_t launch_weighted_checksum(hipStream_t st, u64 *out, const u64 *x, const u64 *w, const u64 *scal, const LimbParams *lp,
@@ -79,7 +87,9 @@ hipError_t launch_compare_sums(hipStream_t st, u32 *flags, const u64 *a, u32 ta,
 // Galois automorphism x -> x^k: coefficient domain (sign-aware scatter) and NTT domain (gather)
 hipError_t launch_automorphism(hipStream_t st, u64 *dst, const u64 *src, const LimbParams *lp, u32 limb0, u32 limbs, u32 units,
                                int logn, u32 k);
-hipError_t launch_automorphism_ntt(hipStream_t st, u64 *dst, const u64 *src, u32 units, int logn, u32 k);
+// optional second (destination, source) pair of the same shape in the same launch
+hipError_t launch_automorphism_ntt(hipStream_t st, u64 *dst, const u64 *src, u32 units, int logn, u32 k, u64 *dst_b = nullptr,
+                                   const u64 *src_b = nullptr);
 
 // ---- baseconv_kernels.hip ------------------------------------------------------
 struct BaseConvPlanDev {

@@ -187,6 +187,12 @@ extern "C" int emu_ntt(u64 *data, int logn, int inverse, int n_poly, int limbs, 
         p.path = path;
     }
     PassArgs a{data, lp.data(), 0u, (u32)limbs, (u32)(n_poly * limbs), (u32)limbs};
+    // fused_dist == -1: the same batch addressed through an explicit unit list (PassArgs::map), in reverse order
+    std::vector<UnitRef> map;
+    if (fused_dist == -1) {
+        for (int u = n_poly * limbs - 1; u >= 0; u--) map.push_back(UnitRef{(u32)u, (u32)(u % limbs)});
+        a.map = map.data();
+    }
     g_max_ratio = 0.0;
     if (fused_dist > 0)
         return path == PATH_F64 ? emu_fused_size<ArithF64>(a, logn, inverse, (u32)fused_dist)

@@ -111,3 +111,20 @@ def test_fused_schedule_matches_oracle(emu, logn, path, bits, dist):
             assert (fwd[p, l] == O.nwt_forward(data[p, l], qs[l], rps[l])).all()
     back = _run(emu, fwd, logn, 1, qs, rps, path, fused_dist=dist)
     assert (back == data).all()
+
+
+@pytest.mark.parametrize("logn", [8, 12, 13, 16])
+@pytest.mark.parametrize("path,bits", [(0, 50), (1, 61)])
+def test_explicit_unit_list_addressing(emu, logn, path, bits):
+    # PassArgs::map (the key switch transforms "every limb of every digit except its own" through it): the same batch
+    # listed explicitly, in reverse order, must give the same transform
+    N = 1 << logn
+    limbs, n_poly = 3, 2
+    qs, rps = _tables(logn, bits, limbs)
+    rng = np.random.default_rng(7 * logn + path)
+    data = np.stack([np.stack([rng.integers(0, q, N, dtype=np.uint64) for q in qs]) for _ in range(n_poly)])
+    fwd = _run(emu, data, logn, 0, qs, rps, path, fused_dist=-1)
+    for p in range(n_poly):
+        for l in range(limbs):
+            assert (fwd[p, l] == O.nwt_forward(data[p, l], qs[l], rps[l])).all()
+    assert (_run(emu, fwd, logn, 1, qs, rps, path, fused_dist=-1) == data).all()
