@@ -589,3 +589,44 @@ def test_largest_sizes(F, eng, O, logn):
         assert (fwd[0, l] == O.nwt_forward(data[0, l], q, O.root_powers(q, logn))).all()
     t.inverse(d)
     assert (d.download() == data).all()
+
+
+def test_two_host_threads_two_streams(F, eng, O):
+    """One context, two host threads, each with its own stream and buffers (the library serialises only its small
+    per-context maps): forward + product + inverse loops must not disturb each other."""
+    import ctypes as C
+    import threading
+    from fhe_reliability_gpu_amd._lib import check, lib
+    logn, N = 13, 1 << 13
+    qs = F.create_moduli(N, [50, 61])
+    t = eng.tables(logn, qs)
+    rng = np.random.default_rng(3)
+    errors = []
+
+    def worker(seed):
+        try:
+            import torch
+            s = torch.cuda.Stream()
+            sp = C.c_void_p(s.cuda_stream)
+            r = np.random.default_rng(seed)
+            a, b = _rand_limbs(r, qs, N, 2), _rand_limbs(r, qs, N, 2)
+            want = np.stack([np.stack([O.polymul_ntt(a[p, l], b[p, l], t.psi[l], q) for l, q in enumerate(qs)]) for p in range(2)])
+            for _ in range(10):
+                da, db, dc = eng.upload(a), eng.upload(b), eng.upload(np.zeros_like(a))
+                check(lib.fhe_ntt_forward_batch(eng._h, da.ptr, t._h, 2, 2, 0, sp))
+                check(lib.fhe_ntt_forward_batch(eng._h, db.ptr, t._h, 2, 2, 0, sp))
+                check(lib.fhe_modmul(eng._h, dc.ptr, da.ptr, db.ptr, t._h, 2, 2, 0, sp))
+                check(lib.fhe_ntt_inverse_batch(eng._h, dc.ptr, t._h, 2, 2, 0, sp))
+                check(lib.fhe_sync(eng._h, sp))
+                if not (dc.download() == want).all():
+                    errors.append(seed)
+        except Exception as e:          # noqa: BLE001 -- reported to the main thread
+            errors.append(repr(e))
+
+    threads = [threading.Thread(target=worker, args=(11 + i,)) for i in range(2)]
+    for th in threads:
+        th.start()
+    for th in threads:
+        th.join()
+    assert not errors, errors
+    del rng
