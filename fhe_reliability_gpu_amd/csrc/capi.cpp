@@ -104,6 +104,7 @@ struct fhe_ctx {
     long long fault_idx = -1;   // one-shot mid-transform bit flip (fhe_ctx_inject_fault)
     int fault_bit = 0;
     int geo = 1;           // column-tile geometry of the two-launch path (ntt_launch.hpp)
+    bool resident = false; // 2^13 / 2^14: one LDS-resident pass instead of two launches (opt-in, see ntt_plan.hpp)
     int fused_variant = 7;   // handoff*2 + stream hint (ntt_launch.hpp); 7 = acquire + nt streaming
     // cyclic tables keyed by (log_n, mod, root, convention)
     std::map<std::tuple<int, u64, u64, int>, std::unique_ptr<fhe_ntt_tables>> cyclic;
@@ -333,7 +334,7 @@ int ntt_batch(fhe_ctx *ctx, u64 *d, const fhe_ntt_tables *t, size_t n_poly, size
             if (e == hipSuccess) e = launch_ntt(st, a, t->log_n, inverse, path, ctx->geo, 1);
             ctx->fault_idx = -1;
         } else {
-            e = launch_ntt(st, a, t->log_n, inverse, path, ctx->geo);
+            e = launch_ntt(st, a, t->log_n, inverse, path, ctx->geo, -1, ctx->resident);
         }
         if (e != hipSuccess) return hip_fail(e, "launch_ntt");
         return FHE_OK;
@@ -383,10 +384,11 @@ int fhe_ctx_create(int device, fhe_ctx **out)
     std::unique_ptr<fhe_ctx> c(new fhe_ctx);
     c->device = device;
     HIP_TRY(hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking));
-    // tuning knobs: FHE_NTT_MODE=twopass|fused, FHE_FUSED_DIST, FHE_FUSED_WGS
+    // tuning knobs: FHE_NTT_MODE=twopass|fused, FHE_FUSED_DIST, FHE_FUSED_WGS, FHE_NTT_RESIDENT=0|1
     if (const char *m = getenv("FHE_NTT_MODE")) c->mode = std::strcmp(m, "fused") == 0 ? 1 : 0;
     if (const char *v = getenv("FHE_FUSED_DIST")) c->fused_dist = (unsigned)std::max(1, atoi(v));
     if (const char *v = getenv("FHE_FUSED_WGS")) c->fused_wgs = (unsigned)std::max(1, atoi(v));
+    if (const char *v = getenv("FHE_NTT_RESIDENT")) c->resident = atoi(v) != 0;
     *out = c.release();
     return FHE_OK;
 }
@@ -412,6 +414,7 @@ int fhe_ctx_set_option(fhe_ctx *ctx, const char *name, long value)
     else if (!std::strcmp(name, "fused_wgs")) ctx->fused_wgs = (unsigned)std::max(1l, value);
     else if (!std::strcmp(name, "fused_variant")) ctx->fused_variant = (int)value;
     else if (!std::strcmp(name, "tile_geo")) ctx->geo = value ? 1 : 0;
+    else if (!std::strcmp(name, "ntt_resident")) ctx->resident = value != 0;
     else if (!std::strcmp(name, "fused_skip_teams")) ctx->fused_skip_teams = (unsigned)value;   // test hook
     else return fail(FHE_ERR_INVALID, "unknown option");
     return FHE_OK;

@@ -160,6 +160,7 @@ template <class A, class ST, int LOGN, int S0, int TC, int NTHREADS, bool INVERS
 struct ColPass {
     typedef A Arith;
     typedef typename A::elem elem;
+    static constexpr int THREADS = NTHREADS;
     static constexpr int P = ST::P;
     static constexpr int NPTS = 1 << P;
     static constexpr int LOGSTRIDE = LOGN - S0 - P;
@@ -242,11 +243,14 @@ struct ColPass {
 // ---------------------------------------------------------------------------
 FHE_HD constexpr u32 row_pad(u32 g) { return g + ((g >> 4) << 1); }
 
+// STAGE_BOTH: also stage the side that is not stride-1 (forward: the input) through a coalesced copy phase (tried for
+// the LDS-resident single pass: no gain, see ntt_plan.hpp; kept as a switch).
 template <class A, class ST, int LOGN, int TR, int NTHREADS, bool INVERSE, int IN_MODE, int OUT_MODE, u32 RED,
-          int SBLK, int COHERENT_IN = 0, bool STREAM = false>
+          int SBLK, int COHERENT_IN = 0, bool STREAM = false, bool STAGE_BOTH = false>
 struct RowPass {
     typedef A Arith;
     typedef typename A::elem elem;
+    static constexpr int THREADS = NTHREADS;
     static constexpr int P = ST::P;
     static constexpr int NPTS = 1 << P;
     static constexpr int S0 = LOGN - P;
@@ -255,7 +259,8 @@ struct RowPass {
     static constexpr int TROWS = TR;
     static constexpr int NSTEP = ST::NSTEP;
     static constexpr bool STAGED = NPTS >= 32;                   // copy phase on the stride-1 side
-    static constexpr int NPHASE = ST::NSTEP + (STAGED ? 1 : 0);
+    static constexpr bool STAGE_IN = STAGED && (INVERSE || STAGE_BOTH), STAGE_OUT = STAGED && (!INVERSE || STAGE_BOTH);
+    static constexpr int NPHASE = ST::NSTEP + (STAGE_IN ? 1 : 0) + (STAGE_OUT ? 1 : 0);
     static constexpr int TILES = (1 << S0) / TR;
 
     // coalesced copy HBM -> LDS (inverse, raw words): 2 points (16 bytes) per lane
@@ -309,12 +314,12 @@ struct RowPass {
     static FHE_D void phase(int tid, u64 *__restrict__ base, elem *__restrict__ lds, TwPtr tw, u32 row0,
                             const typename A::Ctx &c, const Tw &inv_n, TAP *tap = nullptr)
     {
-        if constexpr (STAGED && INVERSE && E == 0) {
+        if constexpr (STAGE_IN && E == 0) {
             copy_in(tid, base, lds);
-        } else if constexpr (STAGED && !INVERSE && E == ST::NSTEP) {
+        } else if constexpr (STAGE_OUT && E == NPHASE - 1) {
             copy_out<TAP>(tid, base, lds, c, tap);
         } else {
-            constexpr int SE = (STAGED && INVERSE) ? E - 1 : E;   // register-step index in execution order
+            constexpr int SE = STAGE_IN ? E - 1 : E;   // register-step index in execution order
             constexpr int F = INVERSE ? ST::NSTEP - 1 - SE : SE;
             constexpr int K = ST::k(F);
             constexpr int R = 1 << K;
@@ -323,8 +328,8 @@ struct RowPass {
             constexpr u32 S = 1u << LOGS;
             constexpr int NSETS = NPTS / R;
             constexpr bool FIRST = SE == 0, LAST = SE == ST::NSTEP - 1;
-            constexpr bool FROM_GLOBAL = FIRST && !(STAGED && INVERSE);
-            constexpr bool TO_GLOBAL = LAST && !(STAGED && !INVERSE);
+            constexpr bool FROM_GLOBAL = FIRST && !STAGE_IN;
+            constexpr bool TO_GLOBAL = LAST && !STAGE_OUT;
             constexpr int U0 = INVERSE ? (P - DONE - K) : DONE;
             FHE_ASSUME(tid >= 0 && tid < NTHREADS);
 #pragma unroll 1

@@ -47,12 +47,60 @@ static hipError_t launch_pass(hipStream_t st, const PassArgs &a)
     return hipGetLastError();
 }
 
+// LDS-resident single pass (ntt_plan.hpp ResidentPlan): dynamic LDS above the 64 KiB static limit
+template <class PASS, int LOGN, bool INV>
+__global__ __launch_bounds__(PASS::THREADS) void k_ntt_resident(PassArgs a)
+{
+    typedef typename PASS::Arith A;
+    extern __shared__ __attribute__((aligned(16))) unsigned char resident_lds[];
+    typename PASS::elem *lds = reinterpret_cast<typename PASS::elem *>(resident_lds);
+    u32 limb, row0 = 0;
+    u64 *base = row_tile<PASS, LOGN>(blockIdx.x, a, limb, row0);
+    const LimbParams &p = a.lp[limb];
+    const typename A::Ctx ctx = A::make_ctx(p);
+    const TwPtr tw = as_global(INV ? p.inv : p.fwd);
+    const Tw inv_n = p.inv_n;
+    const int tid = threadIdx.x;
+    static_assert(PASS::NPHASE == 4 || PASS::NPHASE == 5, "three register steps and one or two copy phases");
+    PASS::template phase<0>(tid, base, lds, tw, row0, ctx, inv_n);
+    __syncthreads();
+    PASS::template phase<1>(tid, base, lds, tw, row0, ctx, inv_n);
+    __syncthreads();
+    PASS::template phase<2>(tid, base, lds, tw, row0, ctx, inv_n);
+    __syncthreads();
+    PASS::template phase<3>(tid, base, lds, tw, row0, ctx, inv_n);
+    if constexpr (PASS::NPHASE > 4) {
+        __syncthreads();
+        PASS::template phase<4>(tid, base, lds, tw, row0, ctx, inv_n);
+    }
+}
+
+template <class A, int LOGN, bool INV>
+static hipError_t launch_resident(hipStream_t st, const PassArgs &a)
+{
+    typedef typename ResidentPass<A, LOGN, INV>::Pass PASS;
+    constexpr size_t bytes = (size_t)PASS::LDS_ELEMS * sizeof(typename PASS::elem);
+    static_assert(bytes <= 160 * 1024, "limb does not fit a CU's LDS");
+    static bool raised = false;   // per instantiation; the attribute is per function, setting it twice is harmless
+    if (!raised) {
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(&k_ntt_resident<PASS, LOGN, INV>),
+                                           hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes);
+        if (e != hipSuccess) return e;
+        raised = true;
+    }
+    hipLaunchKernelGGL((k_ntt_resident<PASS, LOGN, INV>), dim3(a.units * PASS::TILES), dim3(PASS::THREADS), bytes, st, a);
+    return hipGetLastError();
+}
+
 // which: -1 = whole transform, 0 / 1 = only the first / second launch of a two-pass size (used by
 // the fault-injection hook that corrupts the intermediate between the passes)
 template <class A, int LOGN, bool INV, int GEO>
-static hipError_t launch_transform(hipStream_t st, const PassArgs &a, int which)
+static hipError_t launch_transform(hipStream_t st, const PassArgs &a, int which, bool resident)
 {
     typedef Passes<A, LOGN, INV, GEO> PS;
+    if constexpr (ResidentPlan<LOGN>::OK) {
+        if (resident && which == -1) return launch_resident<A, LOGN, INV>(st, a);
+    }
     if constexpr (!PS::G::TWO_PASS) {
         if (which == 1) return hipSuccess;
         return launch_pass<typename PS::Single, LOGN, INV, false>(st, a);
@@ -68,14 +116,14 @@ static hipError_t launch_transform(hipStream_t st, const PassArgs &a, int which)
 }
 
 template <class A>
-static hipError_t launch_size(hipStream_t st, const PassArgs &a, int logn, bool inverse, int geo, int which)
+static hipError_t launch_size(hipStream_t st, const PassArgs &a, int logn, bool inverse, int geo, int which, bool resident)
 {
     if (logn == 16 && geo == 0)   // tuning: the wide-tile geometry is kept for 2^16 only
-        return inverse ? launch_transform<A, 16, true, 0>(st, a, which) : launch_transform<A, 16, false, 0>(st, a, which);
+        return inverse ? launch_transform<A, 16, true, 0>(st, a, which, false) : launch_transform<A, 16, false, 0>(st, a, which, false);
     switch (logn) {
 #define FHE_CASE(L)                                                        \
     case L:                                                                \
-        return inverse ? launch_transform<A, L, true, (L >= 13 ? 1 : 0)>(st, a, which) : launch_transform<A, L, false, (L >= 13 ? 1 : 0)>(st, a, which);
+        return inverse ? launch_transform<A, L, true, (L >= 13 ? 1 : 0)>(st, a, which, resident) : launch_transform<A, L, false, (L >= 13 ? 1 : 0)>(st, a, which, resident);
         FHE_CASE(1) FHE_CASE(2) FHE_CASE(3) FHE_CASE(4) FHE_CASE(5) FHE_CASE(6) FHE_CASE(7) FHE_CASE(8)
         FHE_CASE(9) FHE_CASE(10) FHE_CASE(11) FHE_CASE(12) FHE_CASE(13) FHE_CASE(14) FHE_CASE(15) FHE_CASE(16)
         FHE_CASE(17) FHE_CASE(18) FHE_CASE(19) FHE_CASE(20)
@@ -384,10 +432,11 @@ hipError_t launch_polymul(hipStream_t st, const PassArgs &a, u64 *b, u64 *c, int
 // (Chunking large batches so that the second launch would find the first launch's output in the
 // Infinity Cache was measured and brings nothing: a 512 MiB batch runs at the HBM-streaming rate
 // either way, and splitting costs launches.  One launch pair per call.)
-hipError_t launch_ntt(hipStream_t st, const PassArgs &a, int logn, bool inverse, int path, int geo, int which)
+hipError_t launch_ntt(hipStream_t st, const PassArgs &a, int logn, bool inverse, int path, int geo, int which, bool resident)
 {
     if (a.units == 0) return hipSuccess;
-    return path == PATH_F64 ? launch_size<ArithF64>(st, a, logn, inverse, geo, which) : launch_size<ArithU64>(st, a, logn, inverse, geo, which);
+    return path == PATH_F64 ? launch_size<ArithF64>(st, a, logn, inverse, geo, which, resident)
+                            : launch_size<ArithU64>(st, a, logn, inverse, geo, which, resident);
 }
 
 } // namespace fhe

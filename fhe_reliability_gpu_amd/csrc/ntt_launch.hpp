@@ -9,7 +9,8 @@ namespace fhe {
 // Batched in-place transform of a.units limbs of 2^logn points, all on `path`.
 // geo: 1 = 16-column tiles (default), 0 = widest column tile (kept for 2^16 tuning runs)
 // which: -1 whole transform; 0 / 1 = only the first / second launch of a two-pass size
-hipError_t launch_ntt(hipStream_t st, const PassArgs &a, int logn, bool inverse, int path, int geo = 1, int which = -1);
+// resident (opt-in): sizes whose limb fits a CU's LDS (2^13, 2^14) run as ONE LDS-resident pass when the whole transform is asked for
+hipError_t launch_ntt(hipStream_t st, const PassArgs &a, int logn, bool inverse, int path, int geo = 1, int which = -1, bool resident = false);
 
 // c = a * b mod (x^N + 1, q_l): forward column passes, one launch that finishes both forward transforms,
 // multiplies and starts the inverse, inverse column pass.  a and b are scratch afterwards.

@@ -114,6 +114,36 @@ struct Passes {
                     INVERSE ? IO_LAZY : IO_CANONICAL, INVERSE ? RED_FIRST : RED_SECOND, SB> Row;
 };
 
+// LDS-resident single pass for the sizes just above the 64 KiB static limit (opt-in, "ntt_resident"): a 2^13 / 2^14
+// limb (64 / 128 KiB) still fits one CU's 160 KiB of LDS on gfx950, so the whole transform can run in one workgroup
+// and the limb crosses the fabric once in and once out instead of twice.  Radix-32 register steps (32 points per
+// thread) keep the number of LDS exchanges at two; 2^14 takes a CU's LDS alone (512 threads), 2^13 shares it between
+// two workgroups.  Measured: with one or two workgroups per CU nothing overlaps a workgroup's
+// load, arithmetic and store phases, and the halved traffic does not pay for that except for the 2^13 inverse
+// (0.081 vs 0.105 ms per 128 MiB) -- hence not the default.
+template <int LOGN> struct ResidentPlan {
+    static constexpr bool OK = false;
+    typedef Steps<1, 0, 0> S;
+    static constexpr int THREADS = NTT_THREADS;
+};
+template <> struct ResidentPlan<13> {
+    static constexpr bool OK = true;
+    typedef Steps<5, 4, 4> S;
+    static constexpr int THREADS = 256;
+};
+template <> struct ResidentPlan<14> {
+    static constexpr bool OK = true;
+    typedef Steps<5, 5, 4> S;
+    static constexpr int THREADS = 512;
+};
+template <class A, int LOGN, bool INVERSE>
+struct ResidentPass {
+    typedef ResidentPlan<LOGN> RP;
+    static_assert(!RP::OK || LOGN - RP::S::k(RP::S::NSTEP - 1) == BlkStage<LOGN>::value, "last register step must match the table layout");
+    static constexpr u32 RED = INVERSE ? reduce_mask(0, LOGN, A::INV_FIRST, A::INV_NEXT) : reduce_mask(0, LOGN, A::FWD_FIRST, A::FWD_NEXT);
+    typedef RowPass<A, typename RP::S, LOGN, 1, RP::THREADS, INVERSE, IO_CANONICAL, IO_CANONICAL, RED, BlkStage<LOGN>::value> Pass;
+};
+
 // Block -> work mapping.  One block = one tile of one unit (unit = one limb of one
 // polynomial); the tiles of a unit are adjacent block indices.
 template <class CP, int LOGN>

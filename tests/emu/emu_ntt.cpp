@@ -33,13 +33,15 @@ void emu_pass(const PassArgs &a)
         const LimbParams &p = a.lp[limb];
         auto ctx = A::make_ctx(p);
         const TwPtr tw = as_global(INV ? p.inv : p.fwd);
-        for (int tid = 0; tid < NTT_THREADS; tid++) PASS::template phase<0>(tid, base, lds.data(), tw, row0, ctx, p.inv_n);
+        for (int tid = 0; tid < PASS::THREADS; tid++) PASS::template phase<0>(tid, base, lds.data(), tw, row0, ctx, p.inv_n);
         if constexpr (PASS::NPHASE > 1)
-            for (int tid = 0; tid < NTT_THREADS; tid++) PASS::template phase<1>(tid, base, lds.data(), tw, row0, ctx, p.inv_n);
+            for (int tid = 0; tid < PASS::THREADS; tid++) PASS::template phase<1>(tid, base, lds.data(), tw, row0, ctx, p.inv_n);
         if constexpr (PASS::NPHASE > 2)
-            for (int tid = 0; tid < NTT_THREADS; tid++) PASS::template phase<2>(tid, base, lds.data(), tw, row0, ctx, p.inv_n);
+            for (int tid = 0; tid < PASS::THREADS; tid++) PASS::template phase<2>(tid, base, lds.data(), tw, row0, ctx, p.inv_n);
         if constexpr (PASS::NPHASE > 3)
-            for (int tid = 0; tid < NTT_THREADS; tid++) PASS::template phase<3>(tid, base, lds.data(), tw, row0, ctx, p.inv_n);
+            for (int tid = 0; tid < PASS::THREADS; tid++) PASS::template phase<3>(tid, base, lds.data(), tw, row0, ctx, p.inv_n);
+        if constexpr (PASS::NPHASE > 4)
+            for (int tid = 0; tid < PASS::THREADS; tid++) PASS::template phase<4>(tid, base, lds.data(), tw, row0, ctx, p.inv_n);
         if constexpr (A::PATH == PATH_F64 && false) {
             for (auto v : lds) {
                 double r = std::fabs((double)v) / p.n;
@@ -62,6 +64,18 @@ void emu_transform(const PassArgs &a)
         emu_pass<typename PS::Row, LOGN, INV, false>(a);
         emu_pass<typename PS::Col, LOGN, INV, true>(a);
     }
+}
+
+// LDS-resident single pass of 2^13 / 2^14 (ntt_plan.hpp ResidentPlan)
+template <class A, int LOGN>
+int emu_resident(const PassArgs &a, int inverse)
+{
+    if constexpr (ResidentPlan<LOGN>::OK) {
+        if (inverse) emu_pass<typename ResidentPass<A, LOGN, true>::Pass, LOGN, true, false>(a);
+        else emu_pass<typename ResidentPass<A, LOGN, false>::Pass, LOGN, false, false>(a);
+        return 0;
+    }
+    return -1;
 }
 
 template <class A, int LOGN>
@@ -96,13 +110,13 @@ void emu_tile(const PassArgs &a, u32 unit, u32 tile, std::vector<typename PASS::
     const LimbParams &p = a.lp[limb];
     auto ctx = A::make_ctx(p);
     const TwPtr tw = as_global(INV ? p.inv : p.fwd);
-    for (int tid = 0; tid < NTT_THREADS; tid++) PASS::template phase<0>(tid, base, lds.data(), tw, row0, ctx, p.inv_n);
+    for (int tid = 0; tid < PASS::THREADS; tid++) PASS::template phase<0>(tid, base, lds.data(), tw, row0, ctx, p.inv_n);
     if constexpr (PASS::NPHASE > 1)
-        for (int tid = 0; tid < NTT_THREADS; tid++) PASS::template phase<1>(tid, base, lds.data(), tw, row0, ctx, p.inv_n);
+        for (int tid = 0; tid < PASS::THREADS; tid++) PASS::template phase<1>(tid, base, lds.data(), tw, row0, ctx, p.inv_n);
     if constexpr (PASS::NPHASE > 2)
-        for (int tid = 0; tid < NTT_THREADS; tid++) PASS::template phase<2>(tid, base, lds.data(), tw, row0, ctx, p.inv_n);
+        for (int tid = 0; tid < PASS::THREADS; tid++) PASS::template phase<2>(tid, base, lds.data(), tw, row0, ctx, p.inv_n);
     if constexpr (PASS::NPHASE > 3)
-        for (int tid = 0; tid < NTT_THREADS; tid++) PASS::template phase<3>(tid, base, lds.data(), tw, row0, ctx, p.inv_n);
+        for (int tid = 0; tid < PASS::THREADS; tid++) PASS::template phase<3>(tid, base, lds.data(), tw, row0, ctx, p.inv_n);
 }
 
 template <class A, int LOGN, bool INV>
@@ -194,6 +208,11 @@ extern "C" int emu_ntt(u64 *data, int logn, int inverse, int n_poly, int limbs, 
         a.map = map.data();
     }
     g_max_ratio = 0.0;
+    if (fused_dist == -2) {          // resident pass
+        if (logn == 13) return path == PATH_F64 ? emu_resident<ArithF64, 13>(a, inverse) : emu_resident<ArithU64, 13>(a, inverse);
+        if (logn == 14) return path == PATH_F64 ? emu_resident<ArithF64, 14>(a, inverse) : emu_resident<ArithU64, 14>(a, inverse);
+        return -1;
+    }
     if (fused_dist > 0)
         return path == PATH_F64 ? emu_fused_size<ArithF64>(a, logn, inverse, (u32)fused_dist)
                                 : emu_fused_size<ArithU64>(a, logn, inverse, (u32)fused_dist);

@@ -128,3 +128,23 @@ def test_explicit_unit_list_addressing(emu, logn, path, bits):
         for l in range(limbs):
             assert (fwd[p, l] == O.nwt_forward(data[p, l], qs[l], rps[l])).all()
     assert (_run(emu, fwd, logn, 1, qs, rps, path, fused_dist=-1) == data).all()
+
+
+@pytest.mark.parametrize("logn", [13, 14])
+@pytest.mark.parametrize("path,bits", [(0, 50), (1, 61), (0, 30)])
+def test_lds_resident_single_pass(emu, logn, path, bits):
+    # 2^13 / 2^14: the whole limb in one workgroup's LDS, radix-32 register steps (ntt_plan.hpp ResidentPlan)
+    N = 1 << logn
+    limbs, n_poly = 2, 2
+    qs, rps = _tables(logn, bits, limbs)
+    rng = np.random.default_rng(logn + path)
+    data = np.stack([np.stack([rng.integers(0, q, N, dtype=np.uint64) for q in qs]) for _ in range(n_poly)])
+    data[0, 0, :] = qs[0] - 1
+    fwd = _run(emu, data, logn, 0, qs, rps, path, fused_dist=-2)
+    for p in range(n_poly):
+        for l in range(limbs):
+            assert (fwd[p, l] == O.nwt_forward(data[p, l], qs[l], rps[l])).all()
+    assert (_run(emu, fwd, logn, 1, qs, rps, path, fused_dist=-2) == data).all()
+    inv = _run(emu, data, logn, 1, qs, rps, path, fused_dist=-2)
+    for l in range(limbs):
+        assert (inv[0, l] == O.nwt_inverse(data[0, l], qs[l], rps[l])).all()

@@ -81,6 +81,34 @@ def test_forward_inverse_match_oracle(F, eng, O, logn, bits, mode):
         assert (inv[0, l] == O.nwt_inverse(data[0, l], qs[l], rps[l])).all()
 
 
+@pytest.mark.parametrize("logn", [13, 14])
+def test_resident_and_two_launch_forms_agree(F, eng, O, logn):
+    """"ntt_resident" 1 runs 2^13 / 2^14 as one LDS-resident pass (the limb fits a CU's 160 KiB LDS); the default is the
+    two-launch form the larger sizes use.  Both against the oracle, mixed arithmetic paths, out-of-range words."""
+    N = 1 << logn
+    qs = F.create_moduli(N, [50, 61, 50])
+    t = eng.tables(logn, qs)
+    rps = [O.root_powers(q, logn) for q in qs]
+    rng = np.random.default_rng(logn)
+    data = _rand_limbs(rng, qs, N, 3)
+    data[2, 1, 5] = np.uint64(2**64 - 1)
+    red = data.copy()
+    red[2, 1, 5] %= np.uint64(qs[1])
+    try:
+        for resident in (1, 0):
+            eng.set_option("ntt_resident", resident)
+            d = eng.upload(data)
+            t.forward(d, n_poly=3)
+            fwd = d.download()
+            for p in range(3):
+                for l, q in enumerate(qs):
+                    assert (fwd[p, l] == O.nwt_forward(red[p, l], q, rps[l])).all(), (resident, p, l)
+            t.inverse(d, n_poly=3)
+            assert (d.download() == red).all()
+    finally:
+        eng.set_option("ntt_resident", 0)
+
+
 def test_kat2_phantom_prime_ring(F, eng):
     # SURVEY appendix A4 KAT-2: the dotprod_test ring, first logged Phantom prime
     q, logn = PHANTOM_PRIMES[0], 14
