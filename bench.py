@@ -328,7 +328,7 @@ def main():
                 "ms_per_step_wall": dt * 1e3, "ntt_per_s": units / dt, "GBps_each_way": args.polys * args.limbs * N * 8 / (dt / 2) / 1e9}}
         result["also"].update(pcie_inclusive())
 
-    if rank == 0 and not args.no_cpu:
+    if rank == 0 and world == 1 and not args.no_cpu:      # the CPU leg runs at N = 1 only
         from oracle import cport as O
         rp = O.root_powers(qs[0], LOGN)
         a = pristine[0, 0].cpu().numpy().view(np.uint64)
