@@ -85,3 +85,165 @@ def max_over_ranks(value: float, device=None, group=None) -> float:
     t = torch.tensor([value], dtype=torch.float64, device=device)
     dist.all_reduce(t, op=dist.ReduceOp.MAX, group=group)
     return float(t.item())
+
+
+# ---------------------------------------------------------------------------
+# Key switching with the RNS limbs sharded over ranks (BASELINE configs 4-5).
+#
+# Rank r owns the contiguous slab limb_shard(L + K, world, r) of the L ciphertext primes followed by the K
+# special primes: its limbs of the input, of every key digit and of the result.  NTT / INTT and the products
+# with the key are per limb, so they stay on the owner.  The two base conversions need every limb of their
+# input, hence the only two collectives:
+#   1. all-gather of the input in coefficient form  (L x N)       -> digit extension to the owner's limbs
+#   2. all-gather of the special limbs after the inner product (2 x K x N) -> mod-down to the owner's limbs
+# The per-limb work goes through a small interface (`GpuLimbOps` below: the C ABI on this rank's GPU) so the
+# same orchestration runs over gloo on CPU tensors in the tests, where the interface is backed by the oracle.
+# ---------------------------------------------------------------------------
+def gather_rows(local, bounds: Sequence[Tuple[int, int]], group=None):
+    """All-gather row blocks of unequal height: rank r contributes rows [bounds[r][0], bounds[r][1]) of the
+    result (its ``local`` has that many rows); every rank gets the concatenation."""
+    import torch
+    import torch.distributed as dist
+
+    if not dist.is_available() or not dist.is_initialized() or dist.get_world_size(group) == 1:
+        return local
+    world = dist.get_world_size(group)
+    rows = max(1, max(hi - lo for lo, hi in bounds))
+    pad = torch.zeros((rows,) + tuple(local.shape[1:]), dtype=local.dtype, device=local.device)
+    pad[: local.shape[0]] = local
+    bufs = [torch.empty_like(pad) for _ in range(world)]
+    dist.all_gather(bufs, pad, group=group)
+    return torch.cat([bufs[r][: hi - lo] for r, (lo, hi) in enumerate(bounds)], dim=0)
+
+
+class GpuLimbOps:
+    """Per-limb primitives of the sharded key switch on this rank's GPU (CUDA int64 tensors [rows, N], rows =
+    consecutive table limbs starting at ``start``), through the C ABI on torch's current stream."""
+
+    def __init__(self, eng, tables):
+        self.eng, self.t = eng, tables
+        self._plans = {}
+
+    def _call(self, fn, *args):
+        import ctypes as C
+
+        import torch
+
+        from ._lib import check
+        check(fn(self.eng._h, *args, C.c_void_p(torch.cuda.current_stream().cuda_stream)))
+
+    @staticmethod
+    def _p(x):
+        import ctypes as C
+        return C.c_void_p(x.data_ptr())
+
+    def intt(self, x, start):
+        from ._lib import lib
+        if x.shape[0]:
+            self._call(lib.fhe_ntt_inverse_batch, self._p(x), self.t._h, 1, x.shape[0], start)
+        return x
+
+    def ntt(self, x, start):
+        from ._lib import lib
+        if x.shape[0]:
+            self._call(lib.fhe_ntt_forward_batch, self._p(x), self.t._h, 1, x.shape[0], start)
+        return x
+
+    def baseconv(self, x, mod_in, mod_out):
+        """Exact conversion of the full input rows ``x`` ([len(mod_in), N]) to the moduli ``mod_out``."""
+        import torch
+
+        from ._lib import lib
+        from .engine import BaseConv
+        out = torch.empty((len(mod_out), x.shape[1]), dtype=torch.int64, device=x.device)
+        if mod_out:
+            key = (tuple(mod_in), tuple(mod_out))
+            if key not in self._plans:
+                self._plans[key] = BaseConv(self.eng, list(mod_in), list(mod_out))
+            self._call(lib.fhe_baseconv_exact, self._p(out), self._p(x.contiguous()), self._plans[key]._h, x.shape[1])
+        return out
+
+    def mul_acc(self, acc, a, b, start):
+        from ._lib import lib
+        if acc.shape[0]:
+            self._call(lib.fhe_modmul_acc, self._p(acc), self._p(a.contiguous()), self._p(b.contiguous()), self.t._h, 1, acc.shape[0], start)
+        return acc
+
+    def sub_scale(self, a, b, scal, start):
+        """(a - b) * scal[l] mod q_l, rows = limbs start .. start + rows."""
+        import ctypes as C
+
+        import torch
+
+        from ._lib import lib
+        out = torch.empty_like(a)
+        if a.shape[0]:
+            self._call(lib.fhe_modsub, self._p(out), self._p(a.contiguous()), self._p(b.contiguous()), self.t._h, 1, a.shape[0], start)
+            mul = (C.c_uint64 * a.shape[0])(*[int(s) for s in scal])
+            self._call(lib.fhe_scalar_affine, self._p(out), self._p(out), mul, None, self.t._h, 1, a.shape[0], start)
+        return out
+
+    def zeros(self, rows, n, like):
+        import torch
+        return torch.zeros((rows, n), dtype=torch.int64, device=like.device)
+
+
+def sharded_keyswitch(ops, qs: Sequence[int], L: int, K: int, dnum: int, c_local, evk_local, group=None):
+    """Hybrid RNS key switching (same arithmetic as fhe_keyswitch_apply, CKKS-style mod-down) with limbs sharded.
+
+    qs: the L ciphertext primes followed by the K special primes.  With (mlo, mhi) = limb_shard(L + K, world, rank):
+      c_local   : rows = this rank's ciphertext limbs j in [mlo, min(mhi, L)), NTT form, [rows, N]
+      evk_local : [dnum, 2, mhi - mlo, N], this rank's limbs of every key digit, NTT form
+    Returns (out0_local, out1_local): this rank's ciphertext limbs of the result, NTT form.
+    """
+    import torch
+    import torch.distributed as dist
+
+    multi = dist.is_available() and dist.is_initialized() and dist.get_world_size(group) > 1
+    world = dist.get_world_size(group) if multi else 1
+    rank = dist.get_rank(group) if multi else 0
+    M = L + K
+    alpha = -(-L // dnum)
+    slabs = shard_table(M, world)
+    mlo, mhi = slabs[rank]
+    clo, chi = min(mlo, L), min(mhi, L)                      # owned ciphertext limbs
+    slo, shi = max(mlo, L), max(mhi, L)                      # owned special limbs
+    n = c_local.shape[-1] if c_local.shape[0] else evk_local.shape[-1]
+    c_bounds = [(min(lo, L), min(hi, L)) for lo, hi in slabs]
+    s_bounds = [(max(lo, L) - L, max(hi, L) - L) for lo, hi in slabs]
+
+    # 1. input to coefficient form on its owner, then every rank gets all L limbs
+    coef_local = ops.intt(c_local.clone(), clo)
+    coef = gather_rows(coef_local, c_bounds, group)
+
+    # 2. per digit: extension to this rank's limbs, transform, inner product with this rank's part of the key
+    acc = [ops.zeros(mhi - mlo, n, evk_local) for _ in range(2)]
+    for d in range(dnum):
+        lo, hi = d * alpha, min(L, (d + 1) * alpha)
+        ext = ops.zeros(mhi - mlo, n, evk_local)
+        # owned limbs outside the digit come from the base extension (two runs: below and above the digit) ...
+        for a, b in ((mlo, min(mhi, lo)), (max(mlo, hi), mhi)):
+            if b > a:
+                conv = ops.baseconv(coef[lo:hi], list(qs[lo:hi]), list(qs[a:b]))
+                ext[a - mlo:b - mlo] = ops.ntt(conv, a)
+        # ... the digit's own limbs that this rank owns are the input itself
+        a, b = max(mlo, lo), min(mhi, hi)
+        if b > a:
+            ext[a - mlo:b - mlo] = c_local[a - clo:b - clo]
+        for h in range(2):
+            ops.mul_acc(acc[h], ext, evk_local[d, h], mlo)
+
+    # 3. mod-down: special limbs to coefficient form on their owners, all-gather, conversion to the owned ciphertext limbs
+    outs = []
+    pinv = []
+    for j in range(clo, chi):
+        pm = 1
+        for pk in qs[L:]:
+            pm = pm * (pk % qs[j]) % qs[j]
+        pinv.append(pow(pm, -1, qs[j]))
+    for h in range(2):
+        tP_local = ops.intt(acc[h][slo - mlo:shi - mlo].clone(), slo)
+        tP = gather_rows(tP_local, s_bounds, group)
+        conv = ops.ntt(ops.baseconv(tP, list(qs[L:]), list(qs[clo:chi])), clo)
+        outs.append(ops.sub_scale(acc[h][clo - mlo:chi - mlo], conv, pinv, clo))
+    return outs[0], outs[1]
