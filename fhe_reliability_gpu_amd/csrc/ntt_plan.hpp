@@ -92,7 +92,7 @@ struct PassArgs {
     u32 limbs;              // limbs of each polynomial handled by this launch (same arithmetic path)
     u32 units;              // n_poly * limbs
     u32 poly_stride;        // distance between polynomials in units of one limb (>= limbs)
-    const UnitRef *map;     // optional (two-launch path): units[] given explicitly instead of the [poly][limb] grid --
+    const UnitRef *map = nullptr;     // optional (two-launch path): units[] given explicitly instead of the [poly][limb] grid --
                             // e.g. "every limb of every key-switch digit except the digit's own" in one launch
 };
 
