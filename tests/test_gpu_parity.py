@@ -540,9 +540,11 @@ def test_dotprod_test_cli_matches_reference_log_format():
     assert re.search(r"^Injected bitflip @ idx=\d+, bit=\d+$", r.stderr, re.M)
     m = re.search(r"Elementwise symbol errors: (\d+) / 16384\nElementwise Hamming distance \(bit errors\): (\d+)\n", r.stdout)
     assert m
-    if int(m.group(1)) == 16384:          # a flip in a low-order noise bit can be absorbed; otherwise everything breaks
-        assert 120000 < int(m.group(2)) < 200000      # the reference logs ~158800 (bits1-16_num1.txt:30)
-        assert "✖ MISMATCH detected!" in r.stdout or "✔ Dot product matches CPU result." in r.stdout
+    # ciphertexts are NTT-domain, so any flipped bit of any word spreads over every slot: the reference logs 16384 (791 x)
+    # or 16383 (9 x) corrupted slots in its 800 runs, never a match (reliability_test/data/bits1-16_num1.txt)
+    assert int(m.group(1)) >= 16383
+    assert 120000 < int(m.group(2)) < 200000          # the reference logs ~158800 (bits1-16_num1.txt:30)
+    assert "✖ MISMATCH detected!" in r.stdout
     assert _run_cli("dotprod_test", 1).returncode == 1       # usage error (dotprod_test.cu:190-194)
 
 
