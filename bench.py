@@ -155,6 +155,32 @@ def main():
         },
     }
 
+    # each kernel of the step timed on its own, inside real transforms (the two launches issued as two calls with an event
+    # between them): the column pass and the row pass each move the batch once in and once out, i.e. 16*N bytes per
+    # limb-polynomial per LAUNCH; the transform needs both
+    if args.mode == "twopass":
+        marks = []
+        n_pairs = min(args.steps, 100)
+        for i in range(n_pairs + 5):
+            ev = [torch.cuda.Event(enable_timing=True) for _ in range(3)]
+            eng.set_option("ntt_only_pass", 0)
+            ev[0].record(stream)
+            step()
+            ev[1].record(stream)
+            eng.set_option("ntt_only_pass", 1)
+            step()
+            ev[2].record(stream)
+            if i >= 5:
+                marks.append(ev)
+        eng.set_option("ntt_only_pass", -1)
+        torch.cuda.synchronize()
+        per_launch = {}
+        for k, name in ((0, "column_pass"), (1, "row_pass")):
+            ms = sum(e[k].elapsed_time(e[k + 1]) for e in marks) / len(marks)
+            per_launch[name] = {"avg_launch_ms": ms, "GBps_moved": alg_bytes_per_step / (ms * 1e-3) / 1e9,
+                                "frac_of_peak": alg_bytes_per_step / (ms * 1e-3) / 1e9 / HBM_PEAK_GBS}
+        result["roofline"]["per_launch"] = per_launch
+
     # HBM/fabric bytes per step from the PMC passes committed under profiles/ (same command,
     # FETCH_SIZE doubled as MI355X_MICROARCH.md prescribes and as calibrated on this access
     # pattern, plus WRITE_SIZE); only quoted for the configuration it was collected on

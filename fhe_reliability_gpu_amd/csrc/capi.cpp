@@ -105,6 +105,7 @@ struct fhe_ctx {
     int fault_bit = 0;
     int geo = 1;           // column-tile geometry of the two-launch path (ntt_launch.hpp)
     bool resident = false; // 2^13 / 2^14: one LDS-resident pass instead of two launches (opt-in, see ntt_plan.hpp)
+    int only_pass = -1;    // measurement hook: 0 / 1 = launch only the first / second pass of a two-pass size
     int fused_variant = 7;   // handoff*2 + stream hint (ntt_launch.hpp); 7 = acquire + nt streaming
     // cyclic tables keyed by (log_n, mod, root, convention)
     std::map<std::tuple<int, u64, u64, int>, std::unique_ptr<fhe_ntt_tables>> cyclic;
@@ -334,7 +335,7 @@ int ntt_batch(fhe_ctx *ctx, u64 *d, const fhe_ntt_tables *t, size_t n_poly, size
             if (e == hipSuccess) e = launch_ntt(st, a, t->log_n, inverse, path, ctx->geo, 1);
             ctx->fault_idx = -1;
         } else {
-            e = launch_ntt(st, a, t->log_n, inverse, path, ctx->geo, -1, ctx->resident);
+            e = launch_ntt(st, a, t->log_n, inverse, path, ctx->geo, ctx->only_pass, ctx->resident);
         }
         if (e != hipSuccess) return hip_fail(e, "launch_ntt");
         return FHE_OK;
@@ -415,6 +416,7 @@ int fhe_ctx_set_option(fhe_ctx *ctx, const char *name, long value)
     else if (!std::strcmp(name, "fused_variant")) ctx->fused_variant = (int)value;
     else if (!std::strcmp(name, "tile_geo")) ctx->geo = value ? 1 : 0;
     else if (!std::strcmp(name, "ntt_resident")) ctx->resident = value != 0;
+    else if (!std::strcmp(name, "ntt_only_pass")) ctx->only_pass = value == 0 ? 0 : value == 1 ? 1 : -1;   // bench.py times each kernel with it
     else if (!std::strcmp(name, "fused_skip_teams")) ctx->fused_skip_teams = (unsigned)value;   // test hook
     else return fail(FHE_ERR_INVALID, "unknown option");
     return FHE_OK;
