@@ -36,9 +36,9 @@ FHE_PLAN(14, 3, 3, 0, 4, 4, 0)
 FHE_PLAN(15, 4, 3, 0, 4, 4, 0)
 FHE_PLAN(16, 4, 4, 0, 4, 4, 0)
 FHE_PLAN(17, 4, 4, 0, 3, 3, 3)
-FHE_PLAN(18, 3, 3, 3, 3, 3, 3)
-FHE_PLAN(19, 4, 3, 3, 3, 3, 3)
-FHE_PLAN(20, 4, 3, 3, 4, 3, 3)
+FHE_PLAN(18, 4, 4, 0, 4, 3, 3)
+FHE_PLAN(19, 4, 4, 0, 4, 4, 3)
+FHE_PLAN(20, 4, 4, 0, 4, 4, 4)
 #undef FHE_PLAN
 
 
@@ -75,7 +75,7 @@ template <int LOGN, int GEO = 0> struct PlanGeom {
     static constexpr int PC = PL::Col::P, PR = PL::Row::P;
     static constexpr bool TWO_PASS = PC > 0;
     static constexpr int TC = !TWO_PASS ? 1 : GEO == 0 ? cmin(64, 8192 >> PC) : (PC <= 8 ? 16 : 8);
-    static constexpr int TR = !TWO_PASS ? 1 : PR <= 8 ? 16 : PR == 9 ? 8 : 4;
+    static constexpr int TR = !TWO_PASS ? 1 : PR <= 8 ? 16 : PR == 9 ? 8 : PR == 10 ? 4 : PR == 11 ? 2 : 1;   // 4096 points per row tile
 };
 
 // Entry of an explicit unit list: where the limb-polynomial starts (in units of N words from `data`) and

@@ -91,7 +91,7 @@ int emu_size(const PassArgs &a, int logn, int inverse)
     switch (logn) {
 #define CASE(L) case L: emu_dir<A, L>(a, inverse); return 0;
         CASE(1) CASE(2) CASE(3) CASE(4) CASE(5) CASE(6) CASE(7) CASE(8) CASE(9) CASE(10)
-        CASE(11) CASE(12) CASE(13) CASE(14) CASE(15) CASE(16) CASE(17) CASE(18)
+        CASE(11) CASE(12) CASE(13) CASE(14) CASE(15) CASE(16) CASE(17) CASE(18) CASE(19) CASE(20)
 #undef CASE
     default: return -1;
     }

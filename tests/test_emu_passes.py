@@ -51,7 +51,7 @@ def _tables(logn, bits, limbs):
     return qs, rps
 
 
-@pytest.mark.parametrize("logn", list(range(1, 18)))
+@pytest.mark.parametrize("logn", list(range(1, 21)))
 @pytest.mark.parametrize("path,bits", [(0, 50), (1, 61), (1, 50), (0, 30)])
 def test_emulated_passes_match_oracle(emu, logn, path, bits):
     if logn >= 15 and (path, bits) in ((1, 50), (0, 30)):
