@@ -1,0 +1,263 @@
+// capi_internal.hpp -- shared by the translation units that implement the C ABI (capi*.cpp): the opaque handle
+// types, error reporting, device buffers, trace scopes and the few helpers more than one unit needs.
+#pragma once
+#include "../../include/fhe_mi355x.h"
+
+#include <hip/hip_runtime.h>
+
+#include <algorithm>
+#include <chrono>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <map>
+#include <memory>
+#include <mutex>
+#include <string>
+#include <tuple>
+#include <vector>
+
+#include "host_math.hpp"
+#include "ntt_fused.hpp"
+#include "ntt_launch.hpp"
+
+using namespace fhe;
+
+
+// ---- error reporting (one message per host thread, read through fhe_last_error) ----
+
+inline thread_local std::string g_err;
+
+inline int fail(int code, const std::string &msg)
+{
+    g_err = msg;
+    return code;
+}
+inline int hip_fail(hipError_t e, const char *what)
+{
+    g_err = std::string(what) + ": " + hipGetErrorString(e);
+    return FHE_ERR_HIP;
+}
+#define HIP_TRY(expr)                                          \
+    do {                                                       \
+        hipError_t e_ = (expr);                                \
+        if (e_ != hipSuccess) return hip_fail(e_, #expr);      \
+    } while (0)
+
+struct DevBuf {
+    void *p = nullptr;
+    size_t bytes = 0;
+    ~DevBuf()
+    {
+        if (p) (void)hipFree(p);
+    }
+    hipError_t alloc(size_t n)
+    {
+        if (p) (void)hipFree(p);
+        p = nullptr;
+        bytes = n;
+        return hipMalloc(&p, n ? n : 16);
+    }
+    template <class T> hipError_t upload(const std::vector<T> &v)
+    {
+        hipError_t e = alloc(v.size() * sizeof(T));
+        if (e != hipSuccess) return e;
+        return hipMemcpy(p, v.data(), v.size() * sizeof(T), hipMemcpyHostToDevice);
+    }
+    template <class T> T *as() const { return static_cast<T *>(p); }
+};
+
+struct fhe_ntt_tables {
+    fhe_ctx *ctx = nullptr;
+    int log_n = 0, count = 0;
+    std::vector<u64> q, psi;
+    std::vector<int> path;
+    std::vector<LimbParams> h_lp;
+    DevBuf d_lp, d_tw;
+    bool has_inverse = true;
+};
+
+struct fhe_baseconv {
+    int m = 0, k = 0;
+    bool fast_ok = true;
+    DevBuf mod_in, mod_out, dig, hor, fp_in, fp_out, fast_coef, fast_shoup;
+    BaseConvPlanDev dev{};
+};
+
+struct GarnerTables {
+    DevBuf mod, ratio, pref_lo, pref_hi, inv_pref;
+};
+
+struct fhe_ctx {
+    int device = 0;
+    hipStream_t stream = nullptr;
+    std::mutex mu;
+    // fused-NTT control blocks, one per stream the caller launches on (zeroed on that stream per launch)
+    std::map<hipStream_t, std::unique_ptr<DevBuf>> fused_ctl;
+    int mode = 0;          // 0 = two launches per transform (default), 1 = fused launch (experimental)
+    unsigned fused_dist = 4, fused_wgs = 768;
+    unsigned fused_skip_teams = 0;
+    bool trace_on = false;
+    std::string trace;          // collected trace text (fhe_ctx_trace)
+    long long fault_idx = -1;   // one-shot mid-transform bit flip (fhe_ctx_inject_fault)
+    int fault_bit = 0;
+    int geo = 1;           // column-tile geometry of the two-launch path (ntt_launch.hpp)
+    bool resident = false; // 2^13 / 2^14: one LDS-resident pass instead of two launches (opt-in, see ntt_plan.hpp)
+    int only_pass = -1;    // measurement hook: 0 / 1 = launch only the first / second pass of a two-pass size
+    int fused_variant = 7;   // handoff*2 + stream hint (ntt_launch.hpp); 7 = acquire + nt streaming
+    // cyclic tables keyed by (log_n, mod, root, convention)
+    std::map<std::tuple<int, u64, u64, int>, std::unique_ptr<fhe_ntt_tables>> cyclic;
+    std::map<std::vector<u64>, std::unique_ptr<GarnerTables>> garner;
+};
+
+struct fhe_abft {
+    fhe_ctx *ctx = nullptr;
+    const fhe_ntt_tables *t = nullptr;
+    DevBuf w, what, ninv;       // count x N weights (input side / output side), N^-1 per limb
+    DevBuf win, wout, wout8;    // weights for the fused checksums: twiddle-encoded (ArithU64 limbs) and, for the output side,
+                                // as residues (ArithF64 limbs); N^-1 is folded into the output-side weights
+    DevBuf sum_in, sum_out;     // scratch checksums (grown on demand)
+};
+
+struct fhe_keyswitch {
+    fhe_ctx *ctx = nullptr;
+    const fhe_ntt_tables *t = nullptr;
+    int L = 0, K = 0, dnum = 0, alpha = 0, log_n = 0;
+    u64 plain_modulus = 0;              // BGV: delta must vanish modulo this (0 = CKKS-style flooring)
+    std::vector<u64> t_inv_P, t_mod_Q;  // plain_modulus^-1 mod p_k, plain_modulus mod q_j
+    std::vector<fhe_baseconv *> up;     // per digit: digit primes -> every other prime (ascending index)
+    fhe_baseconv *down = nullptr;       // P -> Q
+    DevBuf pinv;                        // P^-1 mod q_j, j < L
+    DevBuf coef, ext, acc, conv, rot;  // coef [L][N], ext [dnum][M][N], acc [2][M][N], conv [2][L][N]
+    DevBuf up_jobs, down_jobs;         // device job lists: all digit extensions / both mod-down conversions in one launch each
+    int up_max_m = 0, up_max_k = 0;
+    bool up_batched = false;           // every digit plan on the same arithmetic path
+    DevBuf ext_map[2];                 // per arithmetic path: the limbs of ext the forward transform covers
+    u32 ext_units[2] = {0, 0};
+    ~fhe_keyswitch()
+    {
+        for (auto *b : up) fhe_baseconv_destroy(b);
+        fhe_baseconv_destroy(down);
+    }
+};
+
+struct fhe_fourstep {
+    fhe_ctx *ctx = nullptr;
+    u64 n1 = 0, n2 = 0, mod = 0;
+    int log1 = 0, log2 = 0;
+    fhe_ntt_tables *t1 = nullptr, *t2 = nullptr; // sub-transform tables of length n1 / n2
+    DevBuf tw, buf0, buf1;
+    ModConst mc{};
+};
+
+
+
+inline hipStream_t pick(fhe_ctx *ctx, void *stream) { return stream ? static_cast<hipStream_t>(stream) : ctx->stream; }
+
+inline int path_for(u64 q)
+{
+    if (q < 2) return -1;
+    if (q < ((u64)1 << 50)) return PATH_F64;
+    if (q < ((u64)1 << 61)) return PATH_U64;
+    return -1;
+}
+
+inline Tw encode(int path, u64 w, u64 q) { return path == PATH_F64 ? ArithF64::encode(w, q) : ArithU64::encode(w, q); }
+
+// entry-wise inverses of t[1..n-1] mod q by Montgomery's batch trick; false when an
+// entry is not a unit
+inline bool batch_inverse(const u64 *t, size_t n, u64 q, std::vector<u64> &out)
+{
+    out.assign(n, 0);
+    if (n < 2) return true;
+    std::vector<u64> pre(n);
+    u64 acc = 1 % q;
+    for (size_t i = 1; i < n; i++) {
+        pre[i] = acc;
+        acc = host::mul_mod(acc, t[i] % q, q);
+    }
+    u64 inv = host::inv_mod(acc, q);
+    if (!inv && q != 1) return false;
+    for (size_t i = n - 1; i >= 1; i--) {
+        out[i] = host::mul_mod(inv, pre[i], q);
+        inv = host::mul_mod(inv, t[i] % q, q);
+    }
+    return true;
+}
+
+
+
+// one launch per maximal run of limbs that share an arithmetic path
+template <class F> int for_each_run(const fhe_ntt_tables *t, size_t limbs, size_t start_idx, F f)
+{
+    size_t i = 0;
+    while (i < limbs) {
+        size_t j = i + 1;
+        while (j < limbs && t->path[start_idx + j] == t->path[start_idx + i]) j++;
+        int rc = f(i, j - i, t->path[start_idx + i]);
+        if (rc != FHE_OK) return rc;
+        i = j;
+    }
+    return FHE_OK;
+}
+
+// Trace scope: when tracing is on, synchronises the stream at both ends and appends one line.
+struct TraceScope {
+    fhe_ctx *ctx;
+    hipStream_t st;
+    const char *tag;
+    bool frontend;
+    std::chrono::steady_clock::time_point t0;
+    TraceScope(fhe_ctx *c, hipStream_t s, const char *t, bool fe = false) : ctx(c), st(s), tag(t), frontend(fe)
+    {
+        if (!ctx->trace_on) return;
+        (void)hipStreamSynchronize(st);
+        if (frontend) ctx->trace += std::string("frontend: ") + tag + "\n";
+        t0 = std::chrono::steady_clock::now();
+    }
+    ~TraceScope()
+    {
+        if (!ctx->trace_on) return;
+        (void)hipStreamSynchronize(st);
+        const long long us = std::chrono::duration_cast<std::chrono::microseconds>(std::chrono::steady_clock::now() - t0).count();
+        char line[128];
+        // enclosing scopes use SEAL's own "<layer>: TAG[n microseconds]" spelling, which the reference's
+        // tools skip; only leaf steps are "[TAG] total cost" lines (as in profile_framewk/build/sample.txt)
+        if (frontend) std::snprintf(line, sizeof line, "frontend: %s[%lld microseconds]\n", tag, us);
+        else if (!std::strcmp(tag, "KEYSWITCH")) std::snprintf(line, sizeof line, "evaluator: %s[%lld microseconds]\n", tag, us);
+        else std::snprintf(line, sizeof line, "[%s] total cost %lld \xC2\xB5s\n", tag, us);
+        ctx->trace += line;
+    }
+};
+
+inline int check_range(const fhe_ntt_tables *t, size_t n_poly, size_t limbs, size_t start_idx)
+{
+    if (!t) return fail(FHE_ERR_INVALID, "null tables");
+    if (start_idx + limbs > (size_t)t->count) return fail(FHE_ERR_INVALID, "limb range exceeds the table set");
+    if (n_poly * limbs > ((size_t)1 << 24)) return fail(FHE_ERR_INVALID, "batch too large for one launch (max 2^24 limb-polynomials)");
+    return FHE_OK;
+}
+
+
+
+inline ModConst mod_const(u64 q)
+{
+    u64 cr[3];
+    host::const_ratio(q, cr);
+    return ModConst{q, cr[0], cr[1]};
+}
+
+inline int ilog2_exact(u64 v)
+{
+    if (!v || (v & (v - 1))) return -1;
+    return 63 - __builtin_clzll(v);
+}
+
+
+// defined in capi.cpp
+int build_tables(fhe_ctx *ctx, int log_n, const fhe::u64 *q, int count, const fhe::u64 *fwd_rows, bool want_inverse, int force_path,
+                 const fhe::u64 *psi_or_null, fhe_ntt_tables **out);
+int ntt_batch(fhe_ctx *ctx, fhe::u64 *d, const fhe_ntt_tables *t, size_t n_poly, size_t limbs, size_t start_idx, void *stream, bool inverse);
+int pointwise(fhe_ctx *ctx, fhe::u64 *c, const fhe::u64 *a, const fhe::u64 *b, const fhe_ntt_tables *t, size_t n_poly, size_t limbs,
+              size_t start_idx, void *stream, bool acc);
+
