@@ -34,8 +34,8 @@ HBM_PEAK_GBS = 8000.0  # MI355X_MICROARCH.md: HBM3E 8 TB/s spec
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=200)
-    ap.add_argument("--warmup", type=int, default=50)
+    ap.add_argument("--steps", type=int, default=1000)
+    ap.add_argument("--warmup", type=int, default=200)
     ap.add_argument("--polys", type=int, default=256, help="residue polynomials per limb in the batch")
     ap.add_argument("--limbs", type=int, default=1, help="distinct RNS primes per polynomial")
     ap.add_argument("--bits", type=int, default=50, help="prime size (50 = reference; 61 = integer path)")
