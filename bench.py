@@ -214,7 +214,7 @@ def main():
 
     # secondary measurements on rank 0 (not the headline): same kernels, other batch shapes
     if rank == 0 and not args.no_extras and world == 1:
-        def rate(limbs, polys, bits, inverse=False, steps=10):
+        def rate(limbs, polys, bits, inverse=False, steps=300):
             q2 = F.create_moduli(N, [bits] * limbs)
             t2 = eng.tables(LOGN, q2)
             buf = torch.empty((polys, limbs, N), dtype=torch.int64, device="cuda")
@@ -223,7 +223,7 @@ def main():
             torch.cuda.synchronize()
             fn = lib.fhe_ntt_inverse_batch if inverse else lib.fhe_ntt_forward_batch
             call = lambda: check(fn(eng._h, C.c_void_p(buf.data_ptr()), t2._h, polys, limbs, 0, sptr))
-            for _ in range(3):
+            for _ in range(max(3, steps // 4)):
                 call()
             torch.cuda.synchronize()
             a0, a1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
@@ -244,8 +244,8 @@ def main():
             mk = lambda: torch.randint(0, q2[0], (P2, L2, N), generator=g, device="cuda", dtype=torch.int64)
             a, b, c = mk(), mk(), mk()
             pa, pb, pc = (C.c_void_p(x.data_ptr()) for x in (a, b, c))
-            def timed(fn, steps=20):
-                for _ in range(3):
+            def timed(fn, steps=200):
+                for _ in range(50):
                     fn()
                 torch.cuda.synchronize()
                 a0, a1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
@@ -290,7 +290,7 @@ def main():
         result["also"] = {
             "inverse_same_batch": rate(args.limbs, args.polys, args.bits, inverse=True),
             "L16_distinct_primes_x16_polys (configs[2] shape)": rate(16, 16, args.bits),
-            "hbm_streaming_1024_polys_512MiB (exceeds the 256 MiB Infinity Cache)": rate(1, 1024, args.bits, steps=5),
+            "hbm_streaming_1024_polys_512MiB (exceeds the 256 MiB Infinity Cache)": rate(1, 1024, args.bits, steps=60),
             "61bit_prime_integer_path": rate(1, args.polys, 61),
         }
         result["also"].update(pointwise_rates())
