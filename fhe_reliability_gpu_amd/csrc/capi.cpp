@@ -101,6 +101,21 @@ int ntt_batch(fhe_ctx *ctx, u64 *d, const fhe_ntt_tables *t, size_t n_poly, size
             if (e == hipSuccess) e = launch_ntt(st, a, t->log_n, inverse, path, ctx->geo, 1);
             ctx->fault_idx = -1;
         } else {
+            if (ctx->packed_on && ctx->only_pass < 0 && ctx->geo == 1 && ntt_packed_supported(t->log_n, inverse, path)) {
+                DevBuf *sc;
+                {
+                    std::lock_guard<std::mutex> lock(ctx->mu);
+                    auto &slot = ctx->packed[st];
+                    if (!slot) slot.reset(new DevBuf);
+                    sc = slot.get();
+                }
+                const size_t need = (size_t)a.units * ntt_packed_scratch_words() * 8;
+                if (sc->bytes < need) {
+                    HIP_TRY(hipStreamSynchronize(st));     // growing frees the old block
+                    HIP_TRY(sc->alloc(need));
+                }
+                a.scratch = sc->as<u64>();
+            }
             e = launch_ntt(st, a, t->log_n, inverse, path, ctx->geo, ctx->only_pass, ctx->resident);
         }
         if (e != hipSuccess) return hip_fail(e, "launch_ntt");
@@ -141,6 +156,7 @@ int fhe_ctx_create(int device, fhe_ctx **out)
     if (const char *v = getenv("FHE_FUSED_DIST")) c->fused_dist = (unsigned)std::max(1, atoi(v));
     if (const char *v = getenv("FHE_FUSED_WGS")) c->fused_wgs = (unsigned)std::max(1, atoi(v));
     if (const char *v = getenv("FHE_NTT_RESIDENT")) c->resident = atoi(v) != 0;
+    if (const char *v = getenv("FHE_NTT_PACKED")) c->packed_on = atoi(v) != 0;
     *out = c.release();
     return FHE_OK;
 }
@@ -153,6 +169,7 @@ int fhe_ctx_destroy(fhe_ctx *ctx)
     ctx->cyclic.clear();
     ctx->garner.clear();
     ctx->fused_ctl.clear();
+    ctx->packed.clear();
     (void)hipStreamDestroy(ctx->stream);
     delete ctx;
     return FHE_OK;
@@ -167,6 +184,7 @@ int fhe_ctx_set_option(fhe_ctx *ctx, const char *name, long value)
     else if (!std::strcmp(name, "fused_variant")) ctx->fused_variant = (int)value;
     else if (!std::strcmp(name, "tile_geo")) ctx->geo = value ? 1 : 0;
     else if (!std::strcmp(name, "ntt_resident")) ctx->resident = value != 0;
+    else if (!std::strcmp(name, "ntt_packed")) ctx->packed_on = value != 0;
     else if (!std::strcmp(name, "ntt_only_pass")) ctx->only_pass = value == 0 ? 0 : value == 1 ? 1 : -1;   // bench.py times each kernel with it
     else if (!std::strcmp(name, "fused_skip_teams")) ctx->fused_skip_teams = (unsigned)value;   // test hook
     else return fail(FHE_ERR_INVALID, "unknown option");

@@ -94,6 +94,9 @@ struct fhe_ctx {
     std::mutex mu;
     // fused-NTT control blocks, one per stream the caller launches on (zeroed on that stream per launch)
     std::map<hipStream_t, std::unique_ptr<DevBuf>> fused_ctl;
+    // packed hand-off area of the forward 2^16 transform, one per stream the caller launches on
+    std::map<hipStream_t, std::unique_ptr<DevBuf>> packed;
+    bool packed_on = false;   // "ntt_packed"
     int mode = 0;          // 0 = two launches per transform (default), 1 = fused launch (experimental)
     unsigned fused_dist = 4, fused_wgs = 768;
     unsigned fused_skip_teams = 0;

@@ -47,6 +47,66 @@ static hipError_t launch_pass(hipStream_t st, const PassArgs &a)
     return hipGetLastError();
 }
 
+// Forward transform with the packed hand-off (ntt_core.hpp "Packed hand-off"): column pass -> 50-bit blocks in a.scratch,
+// row pass <- those blocks.  The unit number (blockIdx / 16) indexes the scratch and is the same in both launches.
+template <class PASS, int LOGN>
+__global__ __launch_bounds__(NTT_THREADS) void k_ntt_col_packed(PassArgs a)
+{
+    typedef typename PASS::Arith A;
+    static_assert(PASS::PACKABLE, "geometry without a packed form");
+    __shared__ __attribute__((aligned(16))) typename PASS::elem lds[PASS::LDS_ELEMS];
+    u32 limb;
+    u64 *base = col_tile<PASS, LOGN>(blockIdx.x, a, limb);
+    const u32 unit = blockIdx.x / PASS::TILES, tile = blockIdx.x % PASS::TILES;
+    const LimbParams &p = a.lp[limb];
+    const typename A::Ctx ctx = A::make_ctx(p);
+    const TwPtr tw = as_global(p.fwd);
+    const int tid = threadIdx.x;
+    PASS::template phase<0>(tid, base, lds, tw, 0u, ctx, p.inv_n);
+    __syncthreads();
+    u64 chunk[PK_WORDS];
+    PASS::phase_last_packed(tid, lds, tw, 0u, ctx, chunk);
+    __syncthreads();                                        // every thread has read its points: the image becomes the staging area
+    u64 *stage = reinterpret_cast<u64 *>(lds);
+    PASS::pack_stage(tid, stage, chunk);
+    __syncthreads();
+    PASS::pack_copy_out(tid, stage, a.scratch + ((size_t)unit * 256 + (size_t)tile * 16) * PK_BLOCK_WORDS);
+}
+
+template <class PASS, int LOGN>
+__global__ __launch_bounds__(NTT_THREADS) void k_ntt_row_packed(PassArgs a)
+{
+    typedef typename PASS::Arith A;
+    static_assert(PASS::PACKABLE && PASS::NPHASE == 3, "geometry without a packed form");
+    __shared__ __attribute__((aligned(16))) typename PASS::elem lds[PASS::LDS_ELEMS];
+    u32 limb, row0 = 0;
+    u64 *base = row_tile<PASS, LOGN>(blockIdx.x, a, limb, row0);
+    const u32 unit = blockIdx.x / PASS::TILES, tile = blockIdx.x % PASS::TILES;
+    const LimbParams &p = a.lp[limb];
+    const typename A::Ctx ctx = A::make_ctx(p);
+    const TwPtr tw = as_global(p.fwd);
+    const int tid = threadIdx.x;
+    u64 *stage = reinterpret_cast<u64 *>(lds);
+    PASS::unpack_copy_in(tid, stage, a.scratch + (size_t)unit * 256 * PK_BLOCK_WORDS, tile);
+    __syncthreads();
+    typename PASS::elem x[16];
+    PASS::phase_first_packed(tid, stage, tw, row0, ctx, x);
+    __syncthreads();                                        // every thread has unpacked: the staging area becomes the image
+    PASS::phase_first_store(tid, lds, x);
+    __syncthreads();
+    PASS::template phase<1>(tid, base, lds, tw, row0, ctx, p.inv_n);
+    __syncthreads();
+    PASS::template phase<2>(tid, base, lds, tw, row0, ctx, p.inv_n);
+}
+
+// sizes / directions / paths that have the packed form
+template <class A, int LOGN, bool INV, int GEO> constexpr bool packed_ok()
+{
+    typedef Passes<A, LOGN, INV, GEO> PS;
+    if constexpr (PS::G::TWO_PASS && !INV && A::PATH == PATH_F64) return PS::Col::PACKABLE && PS::Row::PACKABLE;
+    return false;
+}
+
 // LDS-resident single pass (ntt_plan.hpp ResidentPlan): dynamic LDS above the 64 KiB static limit
 template <class PASS, int LOGN, bool INV>
 __global__ __launch_bounds__(PASS::THREADS) void k_ntt_resident(PassArgs a)
@@ -100,6 +160,13 @@ static hipError_t launch_transform(hipStream_t st, const PassArgs &a, int which,
     typedef Passes<A, LOGN, INV, GEO> PS;
     if constexpr (ResidentPlan<LOGN>::OK) {
         if (resident && which == -1) return launch_resident<A, LOGN, INV>(st, a);
+    }
+    if constexpr (packed_ok<A, LOGN, INV, GEO>()) {
+        if (a.scratch && which == -1) {
+            hipLaunchKernelGGL((k_ntt_col_packed<typename PS::Col, LOGN>), dim3(a.units * PS::Col::TILES), dim3(NTT_THREADS), 0, st, a);
+            hipLaunchKernelGGL((k_ntt_row_packed<typename PS::Row, LOGN>), dim3(a.units * PS::Row::TILES), dim3(NTT_THREADS), 0, st, a);
+            return hipGetLastError();
+        }
     }
     if constexpr (!PS::G::TWO_PASS) {
         if (which == 1) return hipSuccess;
@@ -428,6 +495,13 @@ hipError_t launch_polymul(hipStream_t st, const PassArgs &a, u64 *b, u64 *c, int
     if (logn >= 13) return launch_ntt(st, pc, logn, true, path, 1, 1);
     return hipSuccess;
 }
+
+// true when launch_ntt would use PassArgs::scratch for this transform (the caller then provides packed_scratch_words per unit)
+bool ntt_packed_supported(int logn, bool inverse, int path)
+{
+    return logn == 16 && !inverse && path == PATH_F64 && packed_ok<ArithF64, 16, false, 1>();
+}
+size_t ntt_packed_scratch_words() { return (size_t)256 * PK_BLOCK_WORDS; }
 
 // (Chunking large batches so that the second launch would find the first launch's output in the
 // Infinity Cache was measured and brings nothing: a 512 MiB batch runs at the HBM-streaming rate

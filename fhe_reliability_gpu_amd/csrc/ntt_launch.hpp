@@ -26,6 +26,11 @@ void ntt_checked_tiles(int logn, u32 *tin, u32 *tout);
 hipError_t launch_ntt_checked(hipStream_t st, const PassArgs &a, const Tw *win, const Tw *wout, const u64 *wout8, u64 *sum_in, u64 *sum_out,
                               int logn, int path, int which = -1);
 
+// packed hand-off between the two launches (forward 2^16, FP64 limbs): when PassArgs::scratch is set (ntt_packed_scratch_words()
+// 64-bit words per unit) the intermediate travels as 50-bit residues in 16x16 blocks instead of 8-byte words in place
+bool ntt_packed_supported(int logn, bool inverse, int path);
+size_t ntt_packed_scratch_words();
+
 // ---- ntt_fused.hip: single-launch variant for two-pass sizes --------------------
 bool fused_supported(int logn);
 size_t fused_ctl_bytes(u32 units);

@@ -94,6 +94,7 @@ struct PassArgs {
     u32 poly_stride;        // distance between polynomials in units of one limb (>= limbs)
     const UnitRef *map = nullptr;     // optional (two-launch path): units[] given explicitly instead of the [poly][limb] grid --
                             // e.g. "every limb of every key-switch digit except the digit's own" in one launch
+    u64 *scratch = nullptr; // optional: packed hand-off area, PK_BLOCK_WORDS * 256 words per unit (ntt_core.hpp)
 };
 
 template <class A, int LOGN, bool INVERSE, int GEO = 0>

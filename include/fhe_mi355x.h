@@ -59,6 +59,8 @@ int fhe_ctx_stream(fhe_ctx *ctx, void **stream_out);
  * and second pass; "fused_wgs" persistent workgroups launched; "fused_variant" hand-off
  * load flavour; "ntt_resident" 1 = sizes 2^13 and 2^14 run as one LDS-resident pass
  * (their limb fits a CU's 160 KiB of LDS; experimental), 0 (default) = two launches like the larger sizes;
+ * "ntt_packed" 1 = the forward 2^16 transform of FP64 limbs hands its intermediate over as packed 50-bit residues
+ * (fewer bytes, more arithmetic: measured slower, experimental), 0 (default) = 8-byte words in place;
  * "tile_geo" column-tile geometry of the two-launch path; "ntt_only_pass" 0 / 1 = launch only the
  * first / second pass of a two-pass size (timing of the individual kernels; -1 = whole transform).  Environment overrides at context creation: FHE_NTT_MODE=twopass|fused,
  * FHE_FUSED_DIST, FHE_FUSED_WGS.  Results are identical in every setting. */

@@ -9,6 +9,7 @@
 //   g++ -O2 -std=c++17 -ffp-contract=off -shared -fPIC -I<csrc> emu_ntt.cpp -o libemu_ntt.so
 #include "ntt_fused.hpp"
 
+#include <array>
 #include <cmath>
 #include <vector>
 
@@ -64,6 +65,69 @@ void emu_transform(const PassArgs &a)
         emu_pass<typename PS::Row, LOGN, INV, false>(a);
         emu_pass<typename PS::Col, LOGN, INV, true>(a);
     }
+}
+
+// forward transform with the packed hand-off (ntt_core.hpp): the kernels' phase order with the per-thread registers that
+// live across a barrier (chunk / x) kept per thread id
+template <class A, int LOGN>
+int emu_packed(const PassArgs &a)
+{
+    typedef Passes<A, LOGN, false, 1> PS;
+    typedef typename PS::Col CP;
+    typedef typename PS::Row RP;
+    if constexpr (PS::G::TWO_PASS && A::PATH == PATH_F64) {
+        if constexpr (CP::PACKABLE && RP::PACKABLE) {
+            std::vector<u64> scratch((size_t)a.units * 256 * PK_BLOCK_WORDS, 0xDEADBEEFDEADBEEFull);
+            std::vector<typename A::elem> lds(cmax(CP::LDS_ELEMS, RP::LDS_ELEMS));
+            u64 *stage = reinterpret_cast<u64 *>(lds.data());
+            for (u32 b = 0; b < a.units * CP::TILES; b++) {
+                u32 limb;
+                u64 *base = col_tile<CP, LOGN>(b, a, limb);
+                const u32 unit = b / CP::TILES, tile = b % CP::TILES;
+                const LimbParams &p = a.lp[limb];
+                auto ctx = A::make_ctx(p);
+                const TwPtr tw = as_global(p.fwd);
+                for (int tid = 0; tid < CP::THREADS; tid++) CP::template phase<0>(tid, base, lds.data(), tw, 0u, ctx, p.inv_n);
+                std::vector<std::array<u64, PK_WORDS>> chunk(CP::THREADS);
+                for (int tid = 0; tid < CP::THREADS; tid++) {
+                    u64 c[PK_WORDS];
+                    CP::phase_last_packed(tid, lds.data(), tw, 0u, ctx, c);
+                    for (int j = 0; j < PK_WORDS; j++) chunk[tid][j] = c[j];
+                }
+                for (int tid = 0; tid < CP::THREADS; tid++) {
+                    u64 c[PK_WORDS];
+                    for (int j = 0; j < PK_WORDS; j++) c[j] = chunk[tid][j];
+                    CP::pack_stage(tid, stage, c);
+                }
+                for (int tid = 0; tid < CP::THREADS; tid++)
+                    CP::pack_copy_out(tid, stage, scratch.data() + ((size_t)unit * 256 + (size_t)tile * 16) * PK_BLOCK_WORDS);
+            }
+            for (u32 b = 0; b < a.units * RP::TILES; b++) {
+                u32 limb, row0 = 0;
+                u64 *base = row_tile<RP, LOGN>(b, a, limb, row0);
+                const u32 unit = b / RP::TILES, tile = b % RP::TILES;
+                const LimbParams &p = a.lp[limb];
+                auto ctx = A::make_ctx(p);
+                const TwPtr tw = as_global(p.fwd);
+                for (int tid = 0; tid < RP::THREADS; tid++) RP::unpack_copy_in(tid, stage, scratch.data() + (size_t)unit * 256 * PK_BLOCK_WORDS, tile);
+                std::vector<std::array<typename A::elem, 16>> xs(RP::THREADS);
+                for (int tid = 0; tid < RP::THREADS; tid++) {
+                    typename A::elem x[16];
+                    RP::phase_first_packed(tid, stage, tw, row0, ctx, x);
+                    for (int r = 0; r < 16; r++) xs[tid][r] = x[r];
+                }
+                for (int tid = 0; tid < RP::THREADS; tid++) {
+                    typename A::elem x[16];
+                    for (int r = 0; r < 16; r++) x[r] = xs[tid][r];
+                    RP::phase_first_store(tid, lds.data(), x);
+                }
+                for (int tid = 0; tid < RP::THREADS; tid++) RP::template phase<1>(tid, base, lds.data(), tw, row0, ctx, p.inv_n);
+                for (int tid = 0; tid < RP::THREADS; tid++) RP::template phase<2>(tid, base, lds.data(), tw, row0, ctx, p.inv_n);
+            }
+            return 0;
+        }
+    }
+    return -1;
 }
 
 // LDS-resident single pass of 2^13 / 2^14 (ntt_plan.hpp ResidentPlan)
@@ -208,6 +272,10 @@ extern "C" int emu_ntt(u64 *data, int logn, int inverse, int n_poly, int limbs, 
         a.map = map.data();
     }
     g_max_ratio = 0.0;
+    if (fused_dist == -3) {          // forward transform with the packed hand-off (2^16, FP64 path)
+        if (logn == 16 && path == PATH_F64 && !inverse) return emu_packed<ArithF64, 16>(a);
+        return -1;
+    }
     if (fused_dist == -2) {          // resident pass
         if (logn == 13) return path == PATH_F64 ? emu_resident<ArithF64, 13>(a, inverse) : emu_resident<ArithU64, 13>(a, inverse);
         if (logn == 14) return path == PATH_F64 ? emu_resident<ArithF64, 14>(a, inverse) : emu_resident<ArithU64, 14>(a, inverse);

@@ -148,3 +148,20 @@ def test_lds_resident_single_pass(emu, logn, path, bits):
     inv = _run(emu, data, logn, 1, qs, rps, path, fused_dist=-2)
     for l in range(limbs):
         assert (inv[0, l] == O.nwt_inverse(data[0, l], qs[l], rps[l])).all()
+
+
+@pytest.mark.parametrize("bits", [50, 30, 49])
+def test_packed_handoff_forward(emu, bits):
+    # forward 2^16 with the 50-bit packed hand-off between the passes (ntt_core.hpp): same words as the oracle; extreme
+    # residues (q - 1 everywhere) exercise every bit of the 50-bit fields
+    logn, N, path = 16, 1 << 16, 0
+    limbs, n_poly = 2, 2
+    qs, rps = _tables(logn, bits, limbs)
+    rng = np.random.default_rng(bits)
+    data = np.stack([np.stack([rng.integers(0, q, N, dtype=np.uint64) for q in qs]) for _ in range(n_poly)])
+    data[0, 0, :] = qs[0] - 1
+    data[1, 1, ::3] = 0
+    fwd = _run(emu, data, logn, 0, qs, rps, path, fused_dist=-3)
+    for p in range(n_poly):
+        for l in range(limbs):
+            assert (fwd[p, l] == O.nwt_forward(data[p, l], qs[l], rps[l])).all()
