@@ -231,6 +231,18 @@ struct ArithF64 {
         const double l = __builtin_fma(a, b, -h);
         return canonical(__builtin_fma(-k, c.n, h) + l, c);
     }
+    // product of two values in this arithmetic's lazy range, result again lazy (|r| < 0.6 q): the fused negacyclic
+    // product multiplies the two forward transforms where they sit in LDS, without a trip through canonical words.
+    // Both factors are folded to |.| <= q/2 first, so h - k*q + l stays an exact integer well below 2^53.
+    static FHE_HD elem mulvar_lazy(elem a, elem b, const Ctx &c)
+    {
+        reduce(a, c);
+        reduce(b, c);
+        const double h = a * b;
+        const double k = __builtin_rint(a * (b * c.ninv));
+        const double l = __builtin_fma(a, b, -h);
+        return __builtin_fma(-k, c.n, h) + l;
+    }
     // running sum of mulmod() / mulmod_w() results (each below 0.9 q in magnitude): fold back every fourth term
     static FHE_HD void lazy_acc(elem &s, elem v, int terms, const Ctx &c)
     {
@@ -291,6 +303,9 @@ struct ArithU64 {
         Y = mulmod(d, t, c);
     }
     static FHE_HD u64 mulvar(u64 x, u64 y, const LimbParams &p) { return barrett128(x * y, mulhi64(x, y), p.q, p.barrett_lo, p.barrett_hi); }
+    // lazy x lazy -> canonical (which is also a valid lazy input of the inverse): factors below 4q < 2^63, so the
+    // 128-bit product is below 2^126 and one Barrett step finishes
+    static FHE_HD elem mulvar_lazy(elem a, elem b, const LimbParams &p) { return barrett128(a * b, mulhi64(a, b), p.q, p.barrett_lo, p.barrett_hi); }
     // running sum of mulmod() results (each in [0, 2q)), kept in [0, 2q)
     static FHE_HD void lazy_acc(elem &s, elem v, int, const Ctx &c)
     {

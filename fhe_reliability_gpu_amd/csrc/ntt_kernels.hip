@@ -404,13 +404,25 @@ FHE_D void inv_steps(int tid, u64 *base, typename IR::elem *lds, TwPtr tw, u32 r
     }
 }
 
+// the row passes of the middle launch: the forward one leaves its results in the LDS image in the arithmetic's LAZY form
+// and the inverse one takes them from there in that form, so the product never goes through canonical words
+template <class A, int LOGN, int GEO>
+struct MidPasses {
+    typedef Passes<A, LOGN, false, GEO> F;
+    typedef Passes<A, LOGN, true, GEO> I;
+    typedef typename F::PL PL;
+    static constexpr bool TWO = F::G::TWO_PASS;
+    static constexpr int TR = TWO ? F::G::TR : 1;
+    static constexpr int SB = BlkStage<LOGN>::value;
+    typedef RowPass<A, typename PL::Row, LOGN, TR, NTT_THREADS, false, TWO ? IO_LAZY : IO_CANONICAL, IO_LAZY, TWO ? F::RED_SECOND : F::RED_FIRST, SB> Fwd;
+    typedef RowPass<A, typename PL::Row, LOGN, TR, NTT_THREADS, true, IO_LAZY, TWO ? IO_LAZY : IO_CANONICAL, I::RED_FIRST, SB> Inv;
+};
+
 template <class A, int LOGN, int GEO>
 __global__ __launch_bounds__(NTT_THREADS) void k_polymul_mid(PolymulArgs pa)
 {
-    typedef Passes<A, LOGN, false, GEO> F;
-    typedef Passes<A, LOGN, true, GEO> I;
-    typedef typename std::conditional<F::G::TWO_PASS, typename F::Row, typename F::Single>::type FR;
-    typedef typename std::conditional<F::G::TWO_PASS, typename I::Row, typename I::Single>::type IR;
+    typedef typename MidPasses<A, LOGN, GEO>::Fwd FR;
+    typedef typename MidPasses<A, LOGN, GEO>::Inv IR;
     static_assert(FR::STAGED && IR::STAGED && FR::LDS_ELEMS == IR::LDS_ELEMS, "fused product needs the staged row pass");
     typedef typename FR::elem elem;
     constexpr int PAIRS = FR::TROWS * FR::NPTS / 2;
@@ -426,15 +438,15 @@ __global__ __launch_bounds__(NTT_THREADS) void k_polymul_mid(PolymulArgs pa)
 
     fwd_steps<FR>(tid, ta, lds, as_global(p.fwd), row0, ctx, inv_n);
     __syncthreads();
-    u64 ra[PER][2];
+    elem ra[PER][2];
 #pragma unroll
     for (int k = 0; k < PER; k++) {
         const int i = tid + k * NTT_THREADS;
         if (PAIRS % NTT_THREADS == 0 || i < PAIRS) {
             const u32 row = (u32)i / (FR::NPTS / 2), g = ((u32)i % (FR::NPTS / 2)) * 2;
             const elem *src = lds + row * FR::ROW_LDS + row_pad(g);
-            ra[k][0] = __builtin_bit_cast(u64, src[0]);
-            ra[k][1] = __builtin_bit_cast(u64, src[1]);
+            ra[k][0] = src[0];
+            ra[k][1] = src[1];
         }
     }
     __syncthreads();
@@ -446,8 +458,13 @@ __global__ __launch_bounds__(NTT_THREADS) void k_polymul_mid(PolymulArgs pa)
         if (PAIRS % NTT_THREADS == 0 || i < PAIRS) {
             const u32 row = (u32)i / (FR::NPTS / 2), g = ((u32)i % (FR::NPTS / 2)) * 2;
             elem *dst = lds + row * FR::ROW_LDS + row_pad(g);
-            dst[0] = __builtin_bit_cast(elem, A::mulvar(ra[k][0], __builtin_bit_cast(u64, dst[0]), p));
-            dst[1] = __builtin_bit_cast(elem, A::mulvar(ra[k][1], __builtin_bit_cast(u64, dst[1]), p));
+            if constexpr (A::PATH == PATH_F64) {
+                dst[0] = A::mulvar_lazy(ra[k][0], dst[0], ctx);
+                dst[1] = A::mulvar_lazy(ra[k][1], dst[1], ctx);
+            } else {
+                dst[0] = A::mulvar_lazy(ra[k][0], dst[0], p);
+                dst[1] = A::mulvar_lazy(ra[k][1], dst[1], p);
+            }
         }
     }
     inv_steps<IR>(tid, pa.c + off, lds, as_global(p.inv), row0, ctx, inv_n);
@@ -457,8 +474,7 @@ template <class A, int LOGN>
 static hipError_t launch_mid(hipStream_t st, const PolymulArgs &pa)
 {
     constexpr int GEO = LOGN >= 13 ? 1 : 0;
-    typedef Passes<A, LOGN, false, GEO> F;
-    typedef typename std::conditional<F::G::TWO_PASS, typename F::Row, typename F::Single>::type FR;
+    typedef typename MidPasses<A, LOGN, GEO>::Fwd FR;
     hipLaunchKernelGGL((k_polymul_mid<A, LOGN, GEO>), dim3(pa.a.units * FR::TILES), dim3(NTT_THREADS), 0, st, pa);
     return hipGetLastError();
 }
