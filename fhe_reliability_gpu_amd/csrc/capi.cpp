@@ -34,7 +34,9 @@ int build_tables(fhe_ctx *ctx, int log_n, const u64 *q, int count, const u64 *fw
         bool inv_ok = false;
         if (want_inverse) inv_ok = batch_inverse(row, N, q[l], inv);
         if (inv_ok) {
-            inv[0] = 1 % q[l];
+            // entry 0 is not a twiddle of the network: it carries N^-1 times the last inverse stage's twiddle (entry 1),
+            // which that stage uses to scale while it multiplies (ntt_core.hpp radix_inv FOLD)
+            inv[0] = host::mul_mod(host::inv_mod((u64)(N % q[l]), q[l]), inv[1 % N], q[l]);
             for (size_t k = 0; k < N; k++) b[tw_stored_index(log_n, (u32)k)] = encode(path, inv[k], q[l]);
         } else {
             for (size_t k = 0; k < N; k++) b[k] = f[k];

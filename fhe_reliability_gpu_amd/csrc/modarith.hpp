@@ -218,6 +218,13 @@ struct ArithF64 {
         X = s;
         Y = mulmod(d, t, c);
     }
+    // last inverse stage with N^-1 folded in: (X, Y) -> ((X + Y) n, (X - Y) wn), n = N^-1, wn = w N^-1
+    static FHE_HD void bfly_inv_scaled(elem &X, elem &Y, const Tw &n, const Tw &wn, const Ctx &c)
+    {
+        double s = X + Y, d = X - Y;
+        X = mulmod(s, n, c);
+        Y = mulmod(d, wn, c);
+    }
     static FHE_HD elem add(elem a, elem b) { return a + b; }
     // product of two canonical residues, canonical result.  The quotient estimate rint(x * (y/q)) is off by
     // less than 0.5 + 0.375 (three roundings on a value below 2^50), so h - k*q + l is an exact integer
@@ -301,6 +308,14 @@ struct ArithU64 {
         u64 d = X - Y + c.two_q;
         X = s >= c.two_q ? s - c.two_q : s;
         Y = mulmod(d, t, c);
+    }
+    // last inverse stage with N^-1 folded in (inputs in [0, 2q), outputs in [0, 2q))
+    static FHE_HD void bfly_inv_scaled(elem &X, elem &Y, const Tw &n, const Tw &wn, const Ctx &c)
+    {
+        u64 s = X + Y;
+        u64 d = X - Y + c.two_q;
+        X = mulmod(s, n, c);
+        Y = mulmod(d, wn, c);
     }
     static FHE_HD u64 mulvar(u64 x, u64 y, const LimbParams &p) { return barrett128(x * y, mulhi64(x, y), p.q, p.barrett_lo, p.barrett_hi); }
     // lazy x lazy -> canonical (which is also a valid lazy input of the inverse): factors below 4q < 2^63, so the

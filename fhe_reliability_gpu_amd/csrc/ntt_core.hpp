@@ -77,8 +77,11 @@ FHE_D void radix_fwd(typename A::elem (&x)[1 << K], TwPtr tw, int s, u32 prefix,
 }
 
 // K inverse stages, undoing radix_fwd: forward stage s+K-1 first.
-template <class A, int K, u32 RED, int U0, int SBLK>
-FHE_D void radix_inv(typename A::elem (&x)[1 << K], TwPtr tw, int s, u32 prefix, const typename A::Ctx &c)
+// FOLD (only where the step ends with forward stage 0, i.e. s == 0, and the pass writes final words): N^-1 is folded
+// into that last stage -- X' = (X + Y) N^-1, Y' = (X - Y) (w N^-1) with the product w N^-1 kept in the inverse
+// table's otherwise unused entry 0 -- instead of multiplying every output afterwards: one product per butterfly less.
+template <class A, int K, u32 RED, int U0, int SBLK, bool FOLD = false>
+FHE_D void radix_inv(typename A::elem (&x)[1 << K], TwPtr tw, int s, u32 prefix, const typename A::Ctx &c, const Tw *inv_n = nullptr)
 {
     constexpr int R = 1 << K;
 #pragma unroll
@@ -89,6 +92,12 @@ FHE_D void radix_inv(typename A::elem (&x)[1 << K], TwPtr tw, int s, u32 prefix,
             for (int r = 0; r < R; r++) A::reduce(x[r], c);
         }
         const int half = R >> (u + 1);
+        if (FOLD && u == 0) {
+            const Tw wn = tw[0];
+#pragma unroll
+            for (int j = 0; j < half; j++) A::bfly_inv_scaled(x[j], x[j + half], *inv_n, wn, c);
+            continue;
+        }
 #pragma unroll
         for (int b = 0; b < (1 << u); b++) {
             const Tw w = tw[tw_index(SBLK, s + u, (prefix << u) + b)];
@@ -131,11 +140,11 @@ FHE_D void convert_in(typename A::elem (&x)[R], u64 (&raw)[R], const typename A:
     }
 }
 
-template <class A, int OUT_MODE, bool INVERSE>
+template <class A, int OUT_MODE, bool INVERSE, bool SCALED = false>
 FHE_D u64 convert_out(typename A::elem x, const typename A::Ctx &c, const Tw &inv_n)
 {
     if (OUT_MODE == IO_LAZY) return A::store_lazy(x);
-    if (INVERSE) return A::canonical(A::mulmod(x, inv_n, c), c);
+    if (INVERSE && !SCALED) return A::canonical(A::mulmod(x, inv_n, c), c);   // SCALED: N^-1 already folded into the last stage
     return A::canonical(x, c);
 }
 
@@ -249,13 +258,14 @@ struct ColPass {
                 for (int r = 0; r < R; r++) x[r] = lds[lidx(g0 + ((u32)r << LOGS), col)];
             }
             const u32 prefix = (hi_prefix << DONE) | a;
-            if (INVERSE) radix_inv<A, K, RED, U0, SBLK>(x, tw, S0 + DONE, prefix, c);
+            constexpr bool FOLD = INVERSE && LAST && OUT_MODE == IO_CANONICAL && S0 + DONE == 0;
+            if (INVERSE) radix_inv<A, K, RED, U0, SBLK, FOLD>(x, tw, S0 + DONE, prefix, c, &inv_n);
             else radix_fwd<A, K, RED, U0, SBLK>(x, tw, S0 + DONE, prefix, c);
             if (LAST) {
 #pragma unroll
                 for (int r = 0; r < R; r++) {
                     u64 *dst = base + (size_t)(g0 + ((u32)r << LOGS)) * STRIDE + col;
-                    const u64 out = convert_out<A, OUT_MODE, INVERSE>(x[r], c, inv_n);
+                    const u64 out = convert_out<A, OUT_MODE, INVERSE, FOLD>(x[r], c, inv_n);
                     if (STREAM && OUT_MODE == IO_CANONICAL) store_stream_u64(dst, out);
                     else *dst = out;
                 }
@@ -430,12 +440,13 @@ struct RowPass {
                     for (int r = 0; r < R; r++) x[r] = lrow[row_pad(g0 + ((u32)r << LOGS))];
                 }
                 const u32 prefix = ((row0 + row) << DONE) | a;
-                if (INVERSE) radix_inv<A, K, RED, U0, SBLK>(x, tw, S0 + DONE, prefix, c);
+                constexpr bool FOLD = INVERSE && LAST && OUT_MODE == IO_CANONICAL && S0 + DONE == 0;
+                if (INVERSE) radix_inv<A, K, RED, U0, SBLK, FOLD>(x, tw, S0 + DONE, prefix, c, &inv_n);
                 else radix_fwd<A, K, RED, U0, SBLK>(x, tw, S0 + DONE, prefix, c);
                 if (LAST) {
 #pragma unroll
                     for (int r = 0; r < R; r++) {
-                        const u64 out = convert_out<A, OUT_MODE, INVERSE>(x[r], c, inv_n);
+                        const u64 out = convert_out<A, OUT_MODE, INVERSE, FOLD>(x[r], c, inv_n);
                         if (TO_GLOBAL) {
                             if (STREAM && OUT_MODE == IO_CANONICAL) store_stream_u64(grow + g0 + ((u32)r << LOGS), out);
                             else grow[g0 + ((u32)r << LOGS)] = out;

@@ -253,6 +253,11 @@ extern "C" int emu_ntt(u64 *data, int logn, int inverse, int n_poly, int limbs, 
             fwd[l][at] = path == PATH_F64 ? ArithF64::encode(w, q[l]) : ArithU64::encode(w, q[l]);
             inv[l][at] = path == PATH_F64 ? ArithF64::encode(wi, q[l]) : ArithU64::encode(wi, q[l]);
         }
+        {   // inverse entry 0: N^-1 times the last inverse stage's twiddle (as capi.cpp build_tables lays it out)
+            const u64 ni0 = invmod(N % q[l], q[l]), w1 = invmod(rp[(size_t)l * N + (N > 1 ? 1 : 0)], q[l]);
+            const u64 wn = (u64)((unsigned __int128)ni0 * w1 % q[l]);
+            inv[l][0] = path == PATH_F64 ? ArithF64::encode(wn, q[l]) : ArithU64::encode(wn, q[l]);
+        }
         LimbParams &p = lp[l];
         p.q = q[l];
         p.two_q = 2 * q[l];
