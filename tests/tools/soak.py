@@ -1,13 +1,13 @@
 """Soak run: structured worst-case-ish inputs for the lazy ranges (all q-1, alternating 0 / q-1 at every period, q/2, sparse
 spikes, random) through every size and both arithmetic paths; forward checked against the oracle, inverse by round trip.
-    python fhe_reliability_gpu_amd/tools/soak.py [seconds]"""
+    python tests/tools/soak.py [seconds]"""
 import os
 import sys
 import time
 
 import numpy as np
 
-sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))  # repo root
 import fhe_reliability_gpu_amd as F  # noqa: E402
 from oracle import cport as O  # noqa: E402
 
