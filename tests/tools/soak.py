@@ -52,6 +52,21 @@ while time.time() < t_end:
     if not (d.download() == data).all():
         bad += 1
         print("MISMATCH round trip", logn, bits)
+    # every 8th case: the fused negacyclic product and the checked transform on the same tables
+    if cases % 8 == 0 and logn >= 5:
+        b = np.stack([rng.integers(0, q, N, dtype=np.uint64) for q in qs])[None]
+        da, db = eng.upload(data), eng.upload(b)
+        t.polymul(da, da, db)
+        got = da.download()
+        for l, q in enumerate(qs):
+            if not (got[0, l] == O.polymul_ntt(data[0, l], b[0, l], t.psi[l], q)).all():
+                bad += 1
+                print("MISMATCH polymul", logn, bits, l)
+        ab = F.Abft(eng, t)
+        d2 = eng.upload(data)
+        if ab.forward_checked(d2).any() or not (d2.download() == fwd).all():
+            bad += 1
+            print("MISMATCH checked transform", logn, bits)
     cases += 1
 print(f"soak: {cases} cases, {bad} mismatches")
 sys.exit(1 if bad else 0)
