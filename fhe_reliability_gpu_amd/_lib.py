@@ -90,6 +90,10 @@ _SIG = {
     "fhe_keyswitch_destroy": (ci, [vp]),
     "fhe_keyswitch_apply": (ci, [vp, vp, vp, vp, vp, vp, vp]),
     "fhe_rotate": (ci, [vp, vp, vp, vp, vp, vp, C.c_uint32, vp, vp]),
+    "fhe_tensor_product": (ci, [vp, vp, vp, vp, vp, vp, vp, vp, vp, sz, sz, vp]),
+    "fhe_relinearize": (ci, [vp, vp, vp, vp, vp, vp, vp, vp, vp]),
+    "fhe_rescale": (ci, [vp, vp, vp, vp, sz, vp]),
+    "fhe_hmult": (ci, [vp, vp, vp, vp, vp, vp, vp, vp, vp, ci, vp]),
     "fhe_modadd": (ci, [vp, vp, vp, vp, vp, sz, sz, sz, vp]),
     "fhe_modsub": (ci, [vp, vp, vp, vp, vp, sz, sz, sz, vp]),
     "fhe_scalar_affine": (ci, [vp, vp, vp, p64, p64, vp, sz, sz, sz, vp]),

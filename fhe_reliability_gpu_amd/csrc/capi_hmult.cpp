@@ -1,0 +1,100 @@
+// capi_hmult.cpp -- homomorphic multiply on top of the key switch: tensor product, relinearisation, rescale
+// (part of the C ABI of include/fhe_mi355x.h; shared pieces in capi_internal.hpp).  This is BASELINE config 4's
+// composite ("hmult with baseConv"): phantom::multiply + relinearize_inplace + mod_switch_to_next_inplace of
+// reliability_test/dotprod_test.cu:113-115, frontends MULTIPLY_CKKS / RELIN of the reference's SEAL traces
+// (profile_framewk/build/data/ckks/16384_4:388-451).
+#include "capi_internal.hpp"
+
+extern "C" {
+
+int fhe_tensor_product(fhe_ctx *ctx, uint64_t *d_d0, uint64_t *d_d1, uint64_t *d_d2, const uint64_t *d_a0, const uint64_t *d_a1,
+                       const uint64_t *d_b0, const uint64_t *d_b1, const fhe_ntt_tables *t, size_t limbs, size_t start_idx, void *stream)
+{
+    if (!ctx || !d_d0 || !d_d1 || !d_d2 || !d_a0 || !d_a1 || !d_b0 || !d_b1) return fail(FHE_ERR_INVALID, "null argument");
+    int rc = check_range(t, 1, limbs, start_idx);
+    if (rc) return rc;
+    HIP_TRY(hipSetDevice(ctx->device));
+    hipStream_t st = pick(ctx, stream);
+    TraceScope tr(ctx, st, "MULTIPLY_CKKS", true);
+    const TensorArgs ta{d_d0, d_d1, d_d2, d_a0, d_a1, d_b0, d_b1, t->d_lp.as<LimbParams>(), (u32)start_idx, (u32)limbs, t->log_n};
+    hipError_t e = launch_tensor(st, ta);
+    if (e != hipSuccess) return hip_fail(e, "launch_tensor");
+    return FHE_OK;
+}
+
+int fhe_relinearize(fhe_ctx *ctx, fhe_keyswitch *p, uint64_t *d_out0, uint64_t *d_out1, const uint64_t *d_d0, const uint64_t *d_d1,
+                    const uint64_t *d_d2, const uint64_t *d_relin_key, void *stream)
+{
+    if (!ctx || !p || !d_d0 || !d_d1 || !d_d2) return fail(FHE_ERR_INVALID, "null argument");
+    HIP_TRY(hipSetDevice(ctx->device));
+    TraceScope tr(ctx, pick(ctx, stream), "RELIN", true);
+    return keyswitch_core(ctx, p, d_out0, d_out1, d_d2, d_relin_key, d_d0, d_d1, stream);
+}
+
+} // extern "C"
+
+// (c - [c]_{q_last}) / q_last on every part: INTT of the last limb, its residues modulo the remaining primes, NTT,
+// subtract, times q_last^-1.  BGV (plain modulus t set on the plan): the removed part is t * [c t^-1]_{q_last}.
+// d_in = [n_parts][L][N]; part i goes to outs[i] ([L-1][N]).
+static int rescale_core(fhe_ctx *ctx, fhe_keyswitch *p, uint64_t *const *outs, const uint64_t *d_in, size_t n_parts, void *stream)
+{
+    if (!ctx || !p || !d_in) return fail(FHE_ERR_INVALID, "null argument");
+    if (n_parts < 1 || n_parts > 3) return fail(FHE_ERR_INVALID, "a ciphertext has 1 to 3 parts");
+    for (size_t i = 0; i < n_parts; i++)
+        if (!outs[i]) return fail(FHE_ERR_INVALID, "null argument");
+    if (p->L < 2 || !p->last) return fail(FHE_ERR_INVALID, "no prime left to drop");
+    HIP_TRY(hipSetDevice(ctx->device));
+    hipStream_t st = pick(ctx, stream);
+    const fhe_ntt_tables *t = p->t;
+    const size_t N = (size_t)1 << p->log_n, L = p->L, R = L - 1;
+    const LimbParams *lp = t->d_lp.as<LimbParams>();
+    u64 *last = p->rs_last.as<u64>(), *delta = p->rs_delta.as<u64>();
+    int rc;
+    hipError_t e;
+    TraceScope tr(ctx, st, "RESCALE", true);
+    HIP_TRY(hipMemcpy2DAsync(last, N * 8, d_in + R * N, L * N * 8, N * 8, n_parts, hipMemcpyDeviceToDevice, st));
+    {
+        TraceScope tr_ntt(ctx, st, "NTT");
+        PassArgs a{last, lp, (u32)R, 1u, (u32)n_parts, 1u};
+        if ((e = launch_ntt(st, a, p->log_n, true, t->path[R], ctx->geo)) != hipSuccess) return hip_fail(e, "launch_ntt");
+    }
+    if (p->plain_modulus && (rc = fhe_scalar_affine(ctx, last, last, &p->t_inv_qlast, nullptr, t, n_parts, 1, R, st))) return rc;
+    e = launch_baseconv_exact_jobs(st, p->rs_jobs.as<BcJob>(), (u32)n_parts, 1, (int)R, p->last->dev.f64 != 0, N);
+    if (e != hipSuccess) return hip_fail(e, "launch_baseconv_exact_jobs");
+    if (p->plain_modulus && (rc = fhe_scalar_affine(ctx, delta, delta, p->t_mod_Q.data(), nullptr, t, n_parts, R, 0, st))) return rc;
+    if ((rc = ntt_batch(ctx, delta, t, n_parts, R, 0, st, false))) return rc;
+    for (size_t part = 0; part < n_parts; part += 2) {
+        const bool two = part + 1 < n_parts;
+        const SubScaleArgs sa{outs[part], two ? outs[part + 1] : nullptr, d_in + part * L * N, delta + part * R * N, nullptr,
+                              p->qlast_inv.as<u64>(), (u64)(L * N), (u64)(R * N), lp, 0u, (u32)R, p->log_n, nullptr};
+        if ((e = launch_sub_scale(st, sa)) != hipSuccess) return hip_fail(e, "launch_sub_scale");
+    }
+    return FHE_OK;
+}
+
+extern "C" {
+
+int fhe_rescale(fhe_ctx *ctx, fhe_keyswitch *p, uint64_t *d_out, const uint64_t *d_in, size_t n_parts, void *stream)
+{
+    if (!p || !d_out || p->L < 2) return fail(FHE_ERR_INVALID, !p || !d_out ? "null argument" : "no prime left to drop");
+    const size_t step = (size_t)(p->L - 1) << p->log_n;
+    uint64_t *outs[3] = {d_out, d_out + step, d_out + 2 * step};
+    return rescale_core(ctx, p, outs, d_in, n_parts, stream);
+}
+
+int fhe_hmult(fhe_ctx *ctx, fhe_keyswitch *p, uint64_t *d_out0, uint64_t *d_out1, const uint64_t *d_a0, const uint64_t *d_a1,
+              const uint64_t *d_b0, const uint64_t *d_b1, const uint64_t *d_relin_key, int rescale, void *stream)
+{
+    if (!ctx || !p || !d_out0 || !d_out1 || !d_relin_key) return fail(FHE_ERR_INVALID, "null argument");
+    if (rescale && p->L < 2) return fail(FHE_ERR_INVALID, "no prime left to drop");
+    const size_t N = (size_t)1 << p->log_n, L = p->L;
+    u64 *d0 = p->hm.as<u64>(), *d1 = d0 + L * N, *d2 = d1 + L * N, *pre = p->hm_pre.as<u64>();
+    int rc;
+    if ((rc = fhe_tensor_product(ctx, d0, d1, d2, d_a0, d_a1, d_b0, d_b1, p->t, L, 0, stream))) return rc;
+    if (!rescale) return fhe_relinearize(ctx, p, d_out0, d_out1, d0, d1, d2, d_relin_key, stream);
+    if ((rc = fhe_relinearize(ctx, p, pre, pre + L * N, d0, d1, d2, d_relin_key, stream))) return rc;
+    uint64_t *outs[3] = {d_out0, d_out1, nullptr};
+    return rescale_core(ctx, p, outs, pre, 2, stream);
+}
+
+} // extern "C"

@@ -137,10 +137,17 @@ struct fhe_keyswitch {
     bool up_batched = false;           // every digit plan on the same arithmetic path
     DevBuf ext_map[2];                 // per arithmetic path: the limbs of ext the forward transform covers
     u32 ext_units[2] = {0, 0};
+    // homomorphic multiply / rescale on top of the key switch (capi_hmult.cpp); rescale needs L >= 2
+    fhe_baseconv *last = nullptr;      // q_{L-1} -> q_0 .. q_{L-2}
+    DevBuf qlast_inv;                  // q_{L-1}^-1 mod q_j, j < L-1
+    DevBuf rs_last, rs_delta, rs_jobs; // [3][N] last limbs in coefficient form, [3][L-1][N] their residues, job list (3 parts)
+    DevBuf hm, hm_pre;                 // [3][L][N] tensor product, [2][L][N] relinearised product before the rescale
+    u64 t_inv_qlast = 0;               // plain_modulus^-1 mod q_{L-1} (BGV)
     ~fhe_keyswitch()
     {
         for (auto *b : up) fhe_baseconv_destroy(b);
         fhe_baseconv_destroy(down);
+        fhe_baseconv_destroy(last);
     }
 };
 
@@ -257,6 +264,9 @@ inline int ilog2_exact(u64 v)
 }
 
 
+// defined in capi_keyswitch.cpp: the key switch of d_c with d_add0 / d_add1 (optional, L x N) added to the two output parts
+int keyswitch_core(fhe_ctx *ctx, fhe_keyswitch *p, uint64_t *d_out0, uint64_t *d_out1, const uint64_t *d_c, const uint64_t *d_evk,
+                   const uint64_t *d_add0, const uint64_t *d_add1, void *stream);
 // defined in capi.cpp
 int build_tables(fhe_ctx *ctx, int log_n, const fhe::u64 *q, int count, const fhe::u64 *fwd_rows, bool want_inverse, int force_path,
                  const fhe::u64 *psi_or_null, fhe_ntt_tables **out);

@@ -98,6 +98,26 @@ int fhe_keyswitch_create(fhe_ctx *ctx, const fhe_ntt_tables *t, int L, int K, in
         HIP_TRY(p->up_jobs.upload(up));
         HIP_TRY(p->down_jobs.upload(down));
     }
+    HIP_TRY(p->hm.alloc(3 * (size_t)L * N * 8));
+    HIP_TRY(p->hm_pre.alloc(2 * (size_t)L * N * 8));
+    if (L >= 2) {
+        // rescale / mod-switch to the next level: drop q_{L-1}
+        const u64 ql = t->q[L - 1];
+        int rc = fhe_baseconv_create(ctx, &ql, 1, t->q.data(), L - 1, &p->last);
+        if (rc) return rc;
+        std::vector<u64> qinv(L - 1);
+        for (int j = 0; j + 1 < L; j++) {
+            qinv[j] = host::inv_mod(ql % t->q[j], t->q[j]);
+            if (!qinv[j]) return fail(FHE_ERR_INVALID, "ciphertext primes must be pairwise coprime");
+        }
+        HIP_TRY(p->qlast_inv.upload(qinv));
+        HIP_TRY(p->rs_last.alloc(3 * N * 8));
+        HIP_TRY(p->rs_delta.alloc(3 * (size_t)(L - 1) * N * 8));
+        std::vector<BcJob> jobs;
+        for (int part = 0; part < 3; part++)
+            jobs.push_back(BcJob{p->last->dev, p->rs_last.as<u64>() + (size_t)part * N, p->rs_delta.as<u64>() + (size_t)part * (L - 1) * N, 0xFFFFFFFFu, 0u});
+        HIP_TRY(p->rs_jobs.upload(jobs));
+    }
     *out = p.release();
     return FHE_OK;
 }
@@ -115,6 +135,11 @@ int fhe_keyswitch_set_plain_modulus(fhe_keyswitch *p, uint64_t plain_modulus)
             p->t_inv_P.push_back(inv);
         }
         for (int j = 0; j < p->L; j++) p->t_mod_Q.push_back(plain_modulus % p->t->q[j]);
+        if (p->L >= 2) {
+            const u64 ql = p->t->q[p->L - 1];
+            p->t_inv_qlast = host::inv_mod(plain_modulus % ql, ql);
+            if (!p->t_inv_qlast) return fail(FHE_ERR_INVALID, "plain modulus must be coprime to the ciphertext primes");
+        }
     }
     return FHE_OK;
 }
@@ -132,18 +157,17 @@ int fhe_keyswitch_destroy(fhe_keyswitch *p)
 // with the launches batched: one INTT, one base extension per digit written straight into the [dnum][M][N]
 // layout, ONE forward transform over every extended limb of every digit (unit list), ONE inner-product launch
 // for all digits and both key halves, and a mod-down that handles both halves per launch where the layout allows.
-static int keyswitch_core(fhe_ctx *ctx, fhe_keyswitch *p, uint64_t *d_out0, uint64_t *d_out1, const uint64_t *d_c, const uint64_t *d_evk,
-                          const uint64_t *d_add0, void *stream);
-
 int fhe_keyswitch_apply(fhe_ctx *ctx, fhe_keyswitch *p, uint64_t *d_out0, uint64_t *d_out1, const uint64_t *d_c,
                         const uint64_t *d_evk, void *stream)
 {
-    return keyswitch_core(ctx, p, d_out0, d_out1, d_c, d_evk, nullptr, stream);
+    return keyswitch_core(ctx, p, d_out0, d_out1, d_c, d_evk, nullptr, nullptr, stream);
 }
 
-// d_add0 (optional, L x N): added to the first output part -- a rotation passes sigma(c0) here
-static int keyswitch_core(fhe_ctx *ctx, fhe_keyswitch *p, uint64_t *d_out0, uint64_t *d_out1, const uint64_t *d_c, const uint64_t *d_evk,
-                          const uint64_t *d_add0, void *stream)
+} // extern "C"
+
+// d_add0 / d_add1 (optional, L x N): added to the output parts -- a rotation passes sigma(c0), a relinearisation d0 and d1
+int keyswitch_core(fhe_ctx *ctx, fhe_keyswitch *p, uint64_t *d_out0, uint64_t *d_out1, const uint64_t *d_c, const uint64_t *d_evk,
+                   const uint64_t *d_add0, const uint64_t *d_add1, void *stream)
 {
     if (!ctx || !p || !d_out0 || !d_out1 || !d_c || !d_evk) return fail(FHE_ERR_INVALID, "null argument");
     HIP_TRY(hipSetDevice(ctx->device));
@@ -206,10 +230,12 @@ static int keyswitch_core(fhe_ctx *ctx, fhe_keyswitch *p, uint64_t *d_out0, uint
     if (e != hipSuccess) return hip_fail(e, "launch_baseconv_exact_jobs");
     if (p->plain_modulus && (rc = fhe_scalar_affine(ctx, conv, conv, p->t_mod_Q.data(), nullptr, t, 2, L, 0, st))) return rc;
     if ((rc = ntt_batch(ctx, conv, t, 2, L, 0, st, false))) return rc;
-    const SubScaleArgs sa{d_out0, d_out1, acc, conv, d_add0, p->pinv.as<u64>(), (u64)(M * N), (u64)(L * N), lp, 0u, (u32)L, p->log_n};
+    const SubScaleArgs sa{d_out0, d_out1, acc, conv, d_add0, p->pinv.as<u64>(), (u64)(M * N), (u64)(L * N), lp, 0u, (u32)L, p->log_n, d_add1};
     if ((e = launch_sub_scale(st, sa)) != hipSuccess) return hip_fail(e, "launch_sub_scale");
     return FHE_OK;
 }
+
+extern "C" {
 
 int fhe_rotate(fhe_ctx *ctx, fhe_keyswitch *p, uint64_t *d_out0, uint64_t *d_out1, const uint64_t *d_c0, const uint64_t *d_c1,
                uint32_t galois_elt, const uint64_t *d_galois_key, void *stream)
@@ -226,7 +252,7 @@ int fhe_rotate(fhe_ctx *ctx, fhe_keyswitch *p, uint64_t *d_out0, uint64_t *d_out
     if (e != hipSuccess) return hip_fail(e, "launch_automorphism_ntt");
     // sigma(c1) is a ciphertext part under sigma(s): switch it back to s with the Galois key; the mod-down's last
     // launch adds sigma(c0) to the first part and writes both parts where the caller wants them
-    return keyswitch_core(ctx, p, d_out0, d_out1, sig1, d_galois_key, sig0, st);
+    return keyswitch_core(ctx, p, d_out0, d_out1, sig1, d_galois_key, sig0, nullptr, st);
 }
 
 } // extern "C"

@@ -19,6 +19,14 @@
 #include <cstddef>
 #include <cstdint>
 
+// Bit-exactness of ArithF64 depends on a*w and fma(a,w,-h) being rounded separately: never let the
+// compiler contract them, whatever flags the build passes (the Makefile also sets -ffp-contract=off).
+#if defined(__clang__)
+#pragma clang fp contract(off)
+#elif defined(__GNUC__)
+#pragma GCC optimize("fp-contract=off")
+#endif
+
 #if defined(__HIPCC__)
 #include <hip/hip_runtime.h>
 #define FHE_HD __host__ __device__ __forceinline__

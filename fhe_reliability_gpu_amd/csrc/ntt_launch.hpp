@@ -49,6 +49,16 @@ struct PointwiseArgs {
 };
 // c = a*b mod q (accumulate = false) or c = (c + a*b) mod q (accumulate = true), per limb
 hipError_t launch_modmul(hipStream_t st, const PointwiseArgs &p, bool accumulate);
+// tensor product of two two-part ciphertexts, NTT domain, per limb: d0 = a0 b0, d1 = a0 b1 + a1 b0, d2 = a1 b1
+// (the coefficient-wise core of phantom::multiply, reliability_test/dotprod_test.cu:113); every operand [limbs][N]
+struct TensorArgs {
+    u64 *d0, *d1, *d2;
+    const u64 *a0, *a1, *b0, *b1;
+    const LimbParams *lp;
+    u32 limb0, limbs;
+    int logn;
+};
+hipError_t launch_tensor(hipStream_t st, const TensorArgs &p);
 hipError_t launch_modadd(hipStream_t st, const PointwiseArgs &p);
 hipError_t launch_modsub(hipStream_t st, const PointwiseArgs &p);
 constexpr int SCALAR_MAX_LIMBS = 64;
@@ -70,7 +80,7 @@ hipError_t launch_bitrev_scale(hipStream_t st, u64 *dst, const u64 *src, int log
 hipError_t launch_fourstep_mid(hipStream_t st, u64 *out, const u64 *in, u32 rows, u32 cols, int log_cols,
                                const u64 *tw, const ModConst &mc, bool with_twiddle);
 hipError_t launch_transpose(hipStream_t st, u64 *out, const u64 *in, u32 rows, u32 cols);
-// out_h = (a_h - b_h) * scal[l] (+ add0 for h = 0) mod q_l over `limbs` limbs from table index limb0, for one half
+// out_h = (a_h - b_h) * scal[l] (+ add_h) mod q_l over `limbs` limbs from table index limb0, for one half
 // (out1 == nullptr) or both halves of a key switch in one launch; a_h = a + h * a_stride, b_h = b + h * b_stride (in words)
 struct SubScaleArgs {
     u64 *out0, *out1;
@@ -79,6 +89,7 @@ struct SubScaleArgs {
     const LimbParams *lp;
     u32 limb0, limbs;
     int logn;
+    const u64 *add1 = nullptr;
 };
 hipError_t launch_sub_scale(hipStream_t st, const SubScaleArgs &p);
 // out[unit] = sum_i w[limb][i] * x[unit][i] mod q_limb (one workgroup per limb-polynomial): the weighted

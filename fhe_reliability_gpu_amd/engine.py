@@ -432,6 +432,42 @@ class KeySwitch:
         check(lib.fhe_rotate(self.eng._h, self._h, o0.ptr, o1.ptr, c0.ptr, c1.ptr, galois_elt, galois_key.ptr, stream))
         return o0, o1
 
+    def set_plain_modulus(self, t: int):
+        """BGV form of the mod-down and of the rescale (0 = CKKS-style flooring)."""
+        check(lib.fhe_keyswitch_set_plain_modulus(self._h, t))
+
+    def _out(self, limbs: int) -> DeviceArray:
+        o = self.eng.alloc(limbs * self.t.N)
+        o.shape = (limbs, self.t.N)
+        return o
+
+    def tensor(self, a0: DeviceArray, a1: DeviceArray, b0: DeviceArray, b1: DeviceArray, stream=None):
+        """``phantom::multiply`` (dotprod_test.cu:113): (d0, d1, d2), each [L][N], NTT domain."""
+        d = [self._out(self.L) for _ in range(3)]
+        check(lib.fhe_tensor_product(self.eng._h, d[0].ptr, d[1].ptr, d[2].ptr, a0.ptr, a1.ptr, b0.ptr, b1.ptr, self.t._h, self.L, 0, stream))
+        return tuple(d)
+
+    def relinearize(self, d0: DeviceArray, d1: DeviceArray, d2: DeviceArray, relin_key: DeviceArray, stream=None):
+        """``relinearize_inplace`` (dotprod_test.cu:114)."""
+        o0, o1 = self._out(self.L), self._out(self.L)
+        check(lib.fhe_relinearize(self.eng._h, self._h, o0.ptr, o1.ptr, d0.ptr, d1.ptr, d2.ptr, relin_key.ptr, stream))
+        return o0, o1
+
+    def rescale(self, c: DeviceArray, n_parts: int = 2, stream=None) -> DeviceArray:
+        """``mod_switch_to_next_inplace`` (dotprod_test.cu:115): [n_parts][L][N] -> [n_parts][L-1][N]."""
+        o = self.eng.alloc(n_parts * (self.L - 1) * self.t.N)
+        o.shape = (n_parts, self.L - 1, self.t.N)
+        check(lib.fhe_rescale(self.eng._h, self._h, o.ptr, c.ptr, n_parts, stream))
+        return o
+
+    def hmult(self, a0: DeviceArray, a1: DeviceArray, b0: DeviceArray, b1: DeviceArray, relin_key: DeviceArray, rescale: bool = True,
+              stream=None):
+        """multiply -> relinearize -> mod_switch_to_next (dotprod_test.cu:113-115) in one call."""
+        limbs = self.L - 1 if rescale else self.L
+        o0, o1 = self._out(limbs), self._out(limbs)
+        check(lib.fhe_hmult(self.eng._h, self._h, o0.ptr, o1.ptr, a0.ptr, a1.ptr, b0.ptr, b1.ptr, relin_key.ptr, 1 if rescale else 0, stream))
+        return o0, o1
+
     def __del__(self):
         try:
             if self._h and self.eng._h:

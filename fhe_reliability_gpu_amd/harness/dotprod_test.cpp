@@ -1,194 +1,224 @@
-// dotprod_test for MI355X -- drop-in for reliability_test/dotprod_test.cu: same command line
-//   dotprod_test <bits_per_symbol> <num_symbols>                       (dotprod_test.cu:190-196)
-// same parameters (BGV, N = 16384, six 50-bit primes of which two special, 20-bit batching plain
-// modulus, :198-204) and the same printed lines (:57-58,70,81,90-91,110,134-139,164-184; logged
-// sample reliability_test/data/bits1-16_num1.txt:4-37), so run_dotprod_simu.sh keeps working.
-// Build with -DGEMM_LOOP for the naive_gemm_test.cu variant (100 encrypted dot products, keys reused),
-// with -DREAL_TEST for dotprod_real_test.cu: no arguments and no software flip (dotprod_real_test.cu:95-96,185),
-// so any mismatch is a hardware fault.
+// Encrypted dot-product harness for the MI355X engine.  Three command lines are built from this file:
+//
+//   dotprod_test <bits_per_symbol> <num_symbols>   one encrypted dot product with software bit flips in x
+//   dotprod_real_test                              (-DREAL_TEST) the same without flips: any mismatch is hardware
+//   naive_gemm_test                                (-DGEMM_LOOP) 100 encrypted dot products, keys reused, no report
+//
+// They stand in for reliability_test/{dotprod_test,dotprod_real_test,naive_gemm_test}.cu: the sweep scripts
+// (run_dotprod_simu.sh:13-38) only append stdout/stderr to log files, so the contract is the command line
+// (dotprod_test.cu:190-196), the parameter set (BGV, N = 16384, 6 x 50-bit primes, 2 special, 20-bit batching
+// modulus, :198-204) and the text of the report lines as logged in reliability_test/data/bits1-16_num1.txt:4-37.
+// Everything numeric happens in the engine through include/phantom_bgv_shim.hpp; this file is a driver:
+// it draws inputs, runs the pipeline stage by stage and formats the report.
+#include <cstdint>
 #include <cstdlib>
 #include <ctime>
 #include <iostream>
+#include <string>
 #include <vector>
 
 #include "../../include/phantom_bgv_shim.hpp"
 
-using namespace std;
-using namespace phantom;
-using namespace phantom::arith;
+namespace {
 
-static EncryptionParameters parms(scheme_type::bgv);
-#ifdef REAL_TEST
-static const char *const PCT = " %";   // dotprod_real_test.cu:173
+using Slots = std::vector<uint64_t>;
+
+enum class Variant { Inject, Real, Loop };
+#if defined(GEMM_LOOP)
+constexpr Variant kVariant = Variant::Loop;
+#elif defined(REAL_TEST)
+constexpr Variant kVariant = Variant::Real;
 #else
-static const char *const PCT = "%";    // dotprod_test.cu:176
+constexpr Variant kVariant = Variant::Inject;
 #endif
 
-// flip bits_per_symbol random bits in each of num_symbols random words of the ciphertext, on the device
-static void inject_bitflip_ciphertext(PhantomCiphertext &ct, int bits_per_symbol, int num_symbols)
+// the ring and the plaintext space every variant uses
+phantom::EncryptionParameters make_parameters()
 {
-    const size_t total = ct.size() * ct.coeff_modulus_size() * ct.poly_modulus_degree();
-    for (int s = 0; s < num_symbols; ++s) {
-        const size_t idx = (size_t)rand() % total;
-        for (int b = 0; b < bits_per_symbol; ++b) {
+    constexpr size_t degree = 16384;
+    phantom::EncryptionParameters p(phantom::scheme_type::bgv);
+    p.set_poly_modulus_degree(degree);
+    p.set_coeff_modulus(phantom::arith::CoeffModulus::Create(degree, std::vector<int>(6, 50)));
+    p.set_special_modulus_size(2);
+    p.set_plain_modulus(phantom::arith::PlainModulus::Batching(degree, 20));
+    return p;
+}
+
+// keys + encoder, generated once per process
+struct Party {
+    PhantomContext &ctx;
+    PhantomSecretKey sk;
+    PhantomPublicKey pk;
+    PhantomRelinKey rlk;
+    PhantomBatchEncoder codec;
+    explicit Party(PhantomContext &c) : ctx(c), sk(c), pk(sk.gen_publickey(c)), rlk(sk.gen_relinkey(c)), codec(c) {}
+
+    PhantomCiphertext seal(const Slots &v)
+    {
+        PhantomCiphertext ct;
+        pk.encrypt_asymmetric(ctx, codec.encode(ctx, v), ct);
+        return ct;
+    }
+    Slots open(const PhantomCiphertext &ct) { return codec.decode(ctx, sk.decrypt(ctx, ct)); }
+};
+
+Slots draw_slots(size_t n)
+{
+    Slots v(n);
+    for (auto &x : v) x = (uint64_t)(rand() % 100);
+    return v;
+}
+
+// the two input vectors are drawn interleaved (x0, y0, x1, y1, ...), as the logged runs were
+void draw_pair(Slots &x, Slots &y)
+{
+    for (size_t i = 0; i < x.size(); ++i) {
+        x[i] = (uint64_t)(rand() % 100);
+        y[i] = (uint64_t)(rand() % 100);
+    }
+}
+
+// XOR `per_word` random bit positions into each of `words` random ciphertext words, on the device
+void corrupt(PhantomCiphertext &ct, int per_word, int words)
+{
+    const size_t span = ct.size() * ct.coeff_modulus_size() * ct.poly_modulus_degree();
+    for (int w = 0; w < words; ++w) {
+        const size_t at = (size_t)rand() % span;
+        for (int k = 0; k < per_word; ++k) {
             const size_t bit = (size_t)rand() % 64;
-            phantom::detail::must(fhe_flip_bit(phantom::detail::engine(), ct.data(), idx, (int)bit, nullptr), "flip");
+            phantom::detail::must(fhe_flip_bit(phantom::detail::engine(), ct.data(), at, (int)bit, nullptr), "flip");
             phantom::detail::must(fhe_sync(phantom::detail::engine(), nullptr), "sync");
-            cerr << "Injected bitflip @ idx=" << idx << ", bit=" << bit << "\n";
+            std::cerr << "Injected bitflip @ idx=" << at << ", bit=" << bit << "\n";
         }
     }
 }
 
-static void dot_product_test(PhantomContext &context, int bits_per_symbol, int num_symbols)
+// slot-wise product x (.) y, relinearised and switched down one level
+PhantomCiphertext hadamard(Party &who, const PhantomCiphertext &x, const PhantomCiphertext &y)
 {
-    cout << "Example: BGV HomMul test" << endl;
+    PhantomCiphertext z = phantom::multiply(who.ctx, x, y);
+    phantom::relinearize_inplace(who.ctx, z, who.rlk);
+    phantom::mod_switch_to_next_inplace(who.ctx, z);
+    return z;
+}
 
-    PhantomSecretKey secret_key(context);
-    PhantomPublicKey public_key = secret_key.gen_publickey(context);
-    PhantomRelinKey relin_keys = secret_key.gen_relinkey(context);
-
-    PhantomBatchEncoder batch_encoder(context);
-    const size_t slot_count = batch_encoder.slot_count(), row_size = slot_count / 2;
-    cout << "Plaintext matrix row size: " << row_size << endl;
-
-    vector<uint64_t> input1(slot_count), input2(slot_count);
-    for (size_t i = 0; i < slot_count; i++) {
-        input1[i] = (uint64_t)(rand() % 100);
-        input2[i] = (uint64_t)(rand() % 100);
+// log2(row) rotate-and-add steps: every slot of a row ends up holding the row's sum
+void fold_rows(Party &who, PhantomCiphertext &z, const PhantomGaloisKey &gk, size_t row)
+{
+    for (size_t shift = 1; shift < row; shift *= 2) {
+        PhantomCiphertext moved = z;
+        phantom::rotate_inplace(who.ctx, moved, (int)shift, gk);
+        phantom::add_inplace(who.ctx, z, moved);
     }
-    cout << "Input vector 1: ";
-    print_vector(input1, 3, 7);
-    cout << "Input vector 2: ";
-    print_vector(input2, 3, 7);
+}
 
-    const uint64_t mod = parms.plain_modulus().value();
-    vector<uint64_t> baseline(slot_count);
-    for (size_t i = 0; i < slot_count; ++i) baseline[i] = (input1[i] * input2[i]) % mod;
+struct Mismatch {
+    size_t slots = 0, bits = 0;
+};
+Mismatch compare(const Slots &want, const Slots &got)
+{
+    Mismatch m;
+    for (size_t i = 0; i < want.size(); ++i) {
+        const uint64_t x = want[i] ^ got[i];
+        m.slots += x != 0;
+        m.bits += (size_t)__builtin_popcountll(x);
+    }
+    return m;
+}
 
-    PhantomPlaintext x_plain = batch_encoder.encode(context, input1), y_plain = batch_encoder.encode(context, input2);
-    PhantomCiphertext x_cipher, y_cipher;
-    public_key.encrypt_asymmetric(context, x_plain, x_cipher);
-    public_key.encrypt_asymmetric(context, y_plain, y_cipher);
+void show(const char *label, const Slots &v)
+{
+    std::cout << label;
+    print_vector(v, 3, 7);
+}
 
-#ifndef REAL_TEST
-    inject_bitflip_ciphertext(x_cipher, bits_per_symbol, num_symbols);
-#else
-    (void)bits_per_symbol, (void)num_symbols, (void)inject_bitflip_ciphertext;
-#endif
+int run_single(PhantomContext &ctx, uint64_t t, int per_word, int words)
+{
+    using std::cout;
+    using std::endl;
+    cout << "Example: BGV HomMul test" << endl;
+    Party who(ctx);
+    const size_t slots = who.codec.slot_count(), row = slots / 2;
+    cout << "Plaintext matrix row size: " << row << endl;
+
+    Slots x(slots), y(slots), want(slots);
+    draw_pair(x, y);
+    show("Input vector 1: ", x);
+    show("Input vector 2: ", y);
+    uint64_t want_sum = 0;
+    for (size_t i = 0; i < slots; ++i) {
+        want[i] = x[i] * y[i] % t;
+        want_sum = (want_sum + want[i]) % t;
+    }
+
+    PhantomCiphertext cx = who.seal(x), cy = who.seal(y);
+    if (kVariant == Variant::Inject) corrupt(cx, per_word, words);
 
     cout << "Compute x * y homomorphically..." << endl;
-    PhantomCiphertext xy_cipher = multiply(context, x_cipher, y_cipher);
-    relinearize_inplace(context, xy_cipher, relin_keys);
-    mod_switch_to_next_inplace(context, xy_cipher);
-
+    PhantomCiphertext cz = hadamard(who, cx, cy);
     {
-        PhantomPlaintext xy_plain = secret_key.decrypt(context, xy_cipher);
-        vector<uint64_t> prod = batch_encoder.decode(context, xy_plain);
-        size_t symbol_errors = 0, bit_errors = 0;
-        for (size_t i = 0; i < slot_count; ++i)
-            if (baseline[i] != prod[i]) {
-                ++symbol_errors;
-                bit_errors += (size_t)__builtin_popcountll(baseline[i] ^ prod[i]);
-            }
-        cout << "Raw product vector: ";
-        print_vector(prod, 3, 7);
-        cout << "CPU baseline      : ";
-        print_vector(baseline, 3, 7);
-        cout << "Elementwise symbol errors: " << symbol_errors << " / " << slot_count << endl;
-        cout << "Elementwise Hamming distance (bit errors): " << bit_errors << endl;
+        const Slots got = who.open(cz);
+        const Mismatch m = compare(want, got);
+        show("Raw product vector: ", got);
+        show("CPU baseline      : ", want);
+        cout << "Elementwise symbol errors: " << m.slots << " / " << slots << endl;
+        cout << "Elementwise Hamming distance (bit errors): " << m.bits << endl;
     }
 
-    PhantomGaloisKey gal_keys = secret_key.create_galois_keys(context);
-    for (size_t step = 1; step < row_size; step <<= 1) {
-        PhantomCiphertext rotated = xy_cipher;
-        rotate_inplace(context, rotated, (int)step, gal_keys);
-        add_inplace(context, xy_cipher, rotated);
-    }
+    const PhantomGaloisKey gk = who.sk.create_galois_keys(ctx);
+    fold_rows(who, cz, gk, row);
+    const Slots folded = who.open(cz);
+    const uint64_t got_sum = (folded[0] + folded[row]) % t;   // the two rows hold their own sums
 
-    PhantomPlaintext dp_plain = secret_key.decrypt(context, xy_cipher);
-    vector<uint64_t> result = batch_encoder.decode(context, dp_plain);
-    const uint64_t result_full = (result[0] + result[row_size]) % mod;
-
-    uint64_t expected = 0;
-    for (size_t i = 0; i < slot_count; ++i) expected = (expected + baseline[i]) % mod;
-
-    const size_t dp_bit_errors = (size_t)__builtin_popcountll(result_full ^ expected);
-    cout << "Decrypted dot product = " << result_full << endl;
-    cout << "Expected (CPU)         = " << expected << endl;
-    cout << "Dot product bit errors (Hamming distance): " << dp_bit_errors << endl;
-    const uint64_t abs_diff = result_full > expected ? result_full - expected : expected - result_full;
-    cout << "Absolute difference   = " << abs_diff << endl;
-    if (expected != 0) cout << "Percentage error      = " << (double)abs_diff / (double)expected * 100.0 << PCT << endl;
-    else cout << "Percentage error      = undefined (expected is zero)" << endl;
-    if (result_full == expected) cout << "✔ Dot product matches CPU result." << endl;
-    else cout << "✖ MISMATCH detected!" << endl;
+    const uint64_t gap = got_sum > want_sum ? got_sum - want_sum : want_sum - got_sum;
+    cout << "Decrypted dot product = " << got_sum << endl;
+    cout << "Expected (CPU)         = " << want_sum << endl;
+    cout << "Dot product bit errors (Hamming distance): " << __builtin_popcountll(got_sum ^ want_sum) << endl;
+    cout << "Absolute difference   = " << gap << endl;
+    if (want_sum == 0) cout << "Percentage error      = undefined (expected is zero)" << endl;
+    else cout << "Percentage error      = " << 100.0 * ((double)gap / (double)want_sum) << (kVariant == Variant::Real ? " %" : "%") << endl;
+    cout << (got_sum == want_sum ? "✔ Dot product matches CPU result." : "✖ MISMATCH detected!") << endl;
+    return 0;
 }
 
-#ifdef GEMM_LOOP
-// naive_gemm_test.cu:25-66,94-100: the same encrypted dot product 100 times with the keys reused
-static vector<uint64_t> encrypted_dot_product(PhantomContext &context, PhantomSecretKey &secret_key, PhantomPublicKey &public_key,
-                                              PhantomRelinKey &relin_keys, PhantomGaloisKey &gal_keys, PhantomBatchEncoder &enc)
+// timing body without a report: fresh inputs every round, keys made once
+int run_loop(PhantomContext &ctx, int rounds)
 {
-    const size_t slot_count = enc.slot_count(), row_size = slot_count / 2;
-    vector<uint64_t> input1(slot_count), input2(slot_count);
-    for (size_t i = 0; i < slot_count; ++i) {
-        input1[i] = (uint64_t)(rand() % 100);
-        input2[i] = (uint64_t)(rand() % 100);
-    }
-    PhantomCiphertext x, y;
-    public_key.encrypt_asymmetric(context, enc.encode(context, input1), x);
-    public_key.encrypt_asymmetric(context, enc.encode(context, input2), y);
-    PhantomCiphertext xy = multiply(context, x, y);
-    relinearize_inplace(context, xy, relin_keys);
-    mod_switch_to_next_inplace(context, xy);
-    for (size_t step = 1; step < row_size; step <<= 1) {
-        PhantomCiphertext tmp = xy;
-        rotate_inplace(context, tmp, (int)step, gal_keys);
-        add_inplace(context, xy, tmp);
-    }
-    return enc.decode(context, secret_key.decrypt(context, xy));
-}
-#endif
-
-int main(int argc, char *argv[])
-{
-    srand((unsigned)time(NULL));
-#if !defined(GEMM_LOOP) && !defined(REAL_TEST)
-    if (argc != 3) {
-        cerr << "Usage: " << argv[0] << " <bits_per_symbol> <num_symbols>\n";
-        return 1;
-    }
-    const int bits_per_symbol = atoi(argv[1]), num_symbols = atoi(argv[2]);
-#elif defined(REAL_TEST)
-    (void)argc;
-    (void)argv;
-    const int bits_per_symbol = 0, num_symbols = 0;
-#else
-    (void)argc;
-    (void)argv;
-#endif
-    const size_t poly_modulus_degree = 16384;
-    parms.set_poly_modulus_degree(poly_modulus_degree);
-    parms.set_coeff_modulus(CoeffModulus::Create(poly_modulus_degree, {50, 50, 50, 50, 50, 50}));
-    parms.set_special_modulus_size(2);
-    parms.set_plain_modulus(PlainModulus::Batching(poly_modulus_degree, 20));
-    try {
-        PhantomContext context(parms);
-        print_parameters(context);
-        cout << endl;
-#ifndef GEMM_LOOP
-        dot_product_test(context, bits_per_symbol, num_symbols);
-#else
-        PhantomSecretKey secret_key(context);
-        PhantomPublicKey public_key = secret_key.gen_publickey(context);
-        PhantomRelinKey relin_keys = secret_key.gen_relinkey(context);
-        PhantomGaloisKey gal_keys = secret_key.create_galois_keys(context);
-        PhantomBatchEncoder enc(context);
-        for (int i = 0; i < 100; ++i) (void)encrypted_dot_product(context, secret_key, public_key, relin_keys, gal_keys, enc);
-#endif
-    } catch (const std::exception &e) {
-        cerr << "ERROR: " << e.what() << "\n";
-        return 1;
+    Party who(ctx);
+    const PhantomGaloisKey gk = who.sk.create_galois_keys(ctx);
+    const size_t slots = who.codec.slot_count();
+    for (int r = 0; r < rounds; ++r) {
+        Slots x(slots), y(slots);
+        draw_pair(x, y);
+        PhantomCiphertext cz = hadamard(who, who.seal(x), who.seal(y));
+        fold_rows(who, cz, gk, slots / 2);
+        (void)who.open(cz);
     }
     return 0;
+}
+
+} // namespace
+
+int main(int argc, char **argv)
+{
+    srand((unsigned)time(nullptr));
+    int per_word = 0, words = 0;
+    if (kVariant == Variant::Inject) {
+        if (argc != 3) {
+            std::cerr << "Usage: " << argv[0] << " <bits_per_symbol> <num_symbols>\n";
+            return 1;
+        }
+        per_word = atoi(argv[1]);
+        words = atoi(argv[2]);
+    }
+    try {
+        const phantom::EncryptionParameters parms = make_parameters();
+        PhantomContext ctx(parms);
+        print_parameters(ctx);
+        std::cout << std::endl;
+        return kVariant == Variant::Loop ? run_loop(ctx, 100) : run_single(ctx, parms.plain_modulus().value(), per_word, words);
+    } catch (const std::exception &e) {
+        std::cerr << "ERROR: " << e.what() << "\n";
+        return 1;
+    }
 }

@@ -230,6 +230,27 @@ int fhe_keyswitch_apply(fhe_ctx *ctx, fhe_keyswitch *p, uint64_t *d_out0, uint64
  * out0 + out1*s ~ sigma(c0 + c1*s). */
 int fhe_rotate(fhe_ctx *ctx, fhe_keyswitch *p, uint64_t *d_out0, uint64_t *d_out1, const uint64_t *d_c0, const uint64_t *d_c1,
                uint32_t galois_elt, const uint64_t *d_galois_key, void *stream);
+/* ---- homomorphic multiply: tensor product, relinearisation, rescale (BASELINE config 4) -------------- */
+/* phantom::multiply (reliability_test/dotprod_test.cu:113; frontend MULTIPLY_CKKS of the SEAL traces,
+ * profile_framewk/build/data/ckks/16384_4:388-389): per limb d0 = a0 b0, d1 = a0 b1 + a1 b0, d2 = a1 b1 on NTT-form
+ * parts of `limbs` limbs each, one pass over the seven operands. */
+int fhe_tensor_product(fhe_ctx *ctx, uint64_t *d_d0, uint64_t *d_d1, uint64_t *d_d2, const uint64_t *d_a0, const uint64_t *d_a1,
+                       const uint64_t *d_b0, const uint64_t *d_b1, const fhe_ntt_tables *t, size_t limbs, size_t start_idx, void *stream);
+/* phantom::relinearize_inplace (dotprod_test.cu:114; frontend RELIN, 16384_4:390-451): (d0, d1, d2) -> (d0 + ks0, d1 + ks1)
+ * with (ks0, ks1) = key switch of d2 under the relinearisation key (layout of fhe_keyswitch_apply's d_evk); the two
+ * additions ride on the key switch's last launch. */
+int fhe_relinearize(fhe_ctx *ctx, fhe_keyswitch *p, uint64_t *d_out0, uint64_t *d_out1, const uint64_t *d_d0, const uint64_t *d_d1,
+                    const uint64_t *d_d2, const uint64_t *d_relin_key, void *stream);
+/* phantom::mod_switch_to_next_inplace (dotprod_test.cu:115) / CKKS rescale: drop the plan's last ciphertext prime,
+ * c' = (c - [c]_{q_last}) / q_last on each of n_parts (1..3) parts; d_in = [n_parts][L][N], d_out = [n_parts][L-1][N],
+ * NTT domain.  With a plain modulus set on the plan (BGV) the removed part is t [c t^-1]_{q_last}, so the plaintext is
+ * kept up to the factor q_last^-1 mod t. */
+int fhe_rescale(fhe_ctx *ctx, fhe_keyswitch *p, uint64_t *d_out, const uint64_t *d_in, size_t n_parts, void *stream);
+/* The three steps above in one call (multiply -> relinearize -> mod_switch, dotprod_test.cu:113-115) on two two-part
+ * ciphertexts of L limbs; rescale != 0: outputs have L-1 limbs, else L.  The plan owns the intermediates. */
+int fhe_hmult(fhe_ctx *ctx, fhe_keyswitch *p, uint64_t *d_out0, uint64_t *d_out1, const uint64_t *d_a0, const uint64_t *d_a1,
+              const uint64_t *d_b0, const uint64_t *d_b1, const uint64_t *d_relin_key, int rescale, void *stream);
+
 /* Operation trace in the line format the reference's tools consume
  * (profile_framewk/build/analyze_trace.py:16-19, sum_trace.py:16-19): "frontend: ROTATE",
  * "[NTT] total cost <n> us" per transform launch, "[MODREDUCTION]/[MULTEVK]/[KEYSWITCH]/[MODSWITCH] total

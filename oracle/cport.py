@@ -52,6 +52,9 @@ def lib() -> C.CDLL:
             "orc_nwt_forward": (None, [p64, C.c_int, u64, p64]),
             "orc_nwt_inverse": (None, [p64, C.c_int, u64, p64]),
             "orc_nwt_forward_batch": (None, [p64, C.c_int, C.c_int, p64, p64]),
+            "orc_nwt_inverse_batch": (None, [p64, C.c_int, C.c_int, p64, p64]),
+            "orc_modmul_batch": (None, [p64, p64, p64, u64, C.c_int, p64, C.c_int]),
+            "orc_set_threads": (C.c_int, [C.c_int]),
             "orc_modmul": (None, [p64, p64, p64, u64, u64]),
             "orc_modmul_acc": (None, [p64, p64, p64, u64, u64]),
             "orc_polymul_naive_negacyclic": (None, [p64, p64, p64, u64, u64]),
@@ -163,9 +166,24 @@ def nwt_forward_batch(a, qs, rps) -> np.ndarray:
 
 def nwt_inverse_batch(a, qs, rps) -> np.ndarray:
     a = _a(a).copy()
-    for l in range(a.shape[0]):
-        a[l] = nwt_inverse(a[l], int(qs[l]), rps[l])
+    qs = _a(qs)
+    rps = _a(rps)
+    L, N = a.shape
+    lib().orc_nwt_inverse_batch(_p(a), int(N).bit_length() - 1, L, _p(qs), _p(rps))
     return a
+
+
+def modmul_batch(a, b, qs, acc=None) -> np.ndarray:
+    """(L, n) limb-wise products mod qs[l]; with ``acc`` (L, n) returns acc + a*b."""
+    a, b, qs = _a(a), _a(b), _a(qs)
+    c = np.zeros_like(a) if acc is None else _a(acc).copy()
+    lib().orc_modmul_batch(_p(c), _p(a), _p(b), a.shape[1], a.shape[0], _p(qs), 0 if acc is None else 1)
+    return c
+
+
+def set_threads(n: int = 0) -> int:
+    """Worker threads of the batch helpers (limb-parallel, OpenMP); 0 = query.  1 = the scalar port."""
+    return int(lib().orc_set_threads(n))
 
 
 def modmul(a, b, mod: int) -> np.ndarray:

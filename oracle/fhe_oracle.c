@@ -513,29 +513,46 @@ void orc_crt_garner(u64 *x_lo, u64 *x_hi, const u64 *residues, const u64 *moduli
 void orc_baseconv_exact(u64 *out, const u64 *residues, const u64 *mod_in, int m,
                         const u64 *mod_out, int k, u64 N)
 {
-    u64 c[64];
-    for (u64 i = 0; i < N; i++) {
+    /* constants of the digit recurrence, once per call: pin[l][j] = p_0..p_{l-1} mod p_j (l <= j),
+     * inv[j] = (p_0..p_{j-1})^-1 mod p_j, pout[l][o] = p_0..p_{l-1} mod q_o */
+    u64 *pin = (u64 *)malloc(sizeof(u64) * (size_t)m * (size_t)m);
+    u64 *pout = (u64 *)malloc(sizeof(u64) * (size_t)m * (size_t)k);
+    u64 inv[64];
+    for (int j = 0; j < m; j++) {
+        u64 pj = mod_in[j], pref = 1 % pj;
+        for (int l = 0; l < j; l++) {
+            pin[(size_t)l * m + j] = pref;
+            pref = orc_mulmod(pref, mod_in[l] % pj, pj);
+        }
+        inv[j] = j ? orc_invmod(pref, pj) : 1 % pj;
+    }
+    for (int o = 0; o < k; o++) {
+        u64 q = mod_out[o], pref = 1 % q;
+        for (int l = 0; l < m; l++) {
+            pout[(size_t)l * k + o] = pref;
+            pref = orc_mulmod(pref, mod_in[l] % q, q);
+        }
+    }
+#pragma omp parallel for schedule(static)
+    for (long long ii = 0; ii < (long long)N; ii++) {
+        const u64 i = (u64)ii;
+        u64 c[64];
         /* digits with exact (not wrapped) prefix residues */
         c[0] = residues[i] % mod_in[0];
         for (int j = 1; j < m; j++) {
-            u64 pj = mod_in[j], t = residues[(u64)j * N + i] % pj, pref = 1 % pj;
+            u64 pj = mod_in[j], t = residues[(u64)j * N + i] % pj;
             u64 acc = 0;
-            for (int l = 0; l < j; l++) {
-                acc = orc_addmod(acc, orc_mulmod(c[l] % pj, pref, pj), pj);
-                pref = orc_mulmod(pref, mod_in[l] % pj, pj);
-            }
-            /* here pref = prod_{l<j} p_l mod p_j */
-            c[j] = orc_mulmod(orc_submod(t, acc, pj), orc_invmod(pref, pj), pj);
+            for (int l = 0; l < j; l++) acc = orc_addmod(acc, orc_mulmod(c[l] % pj, pin[(size_t)l * m + j], pj), pj);
+            c[j] = orc_mulmod(orc_submod(t, acc, pj), inv[j], pj);
         }
         for (int o = 0; o < k; o++) {
-            u64 q = mod_out[o], pref = 1 % q, acc = 0;
-            for (int l = 0; l < m; l++) {
-                acc = orc_addmod(acc, orc_mulmod(c[l] % q, pref, q), q);
-                pref = orc_mulmod(pref, mod_in[l] % q, q);
-            }
+            u64 q = mod_out[o], acc = 0;
+            for (int l = 0; l < m; l++) acc = orc_addmod(acc, orc_mulmod(c[l] % q, pout[(size_t)l * k + o], q), q);
             out[(u64)o * N + i] = acc;
         }
     }
+    free(pin);
+    free(pout);
 }
 
 /* rfhe_framewk/src/baseConv.py:10-40 (bConv): out[i][k] = sum_j ((r_j * Phat_j * inv_j) mod q_k),
@@ -608,9 +625,44 @@ void orc_bsgs_hadamard_mod(u64 *y, const u64 *M_blocks, const u64 *v, int k, int
 /* ------------------------------------------------------------------ */
 
 /* `limbs` forward transforms, limb-major L x N, limb l with rp + l*N
- * (the loop nwt_2d_radix8_forward_inplace replaces, ntt_test.cu:95). */
+ * (the loop nwt_2d_radix8_forward_inplace replaces, ntt_test.cu:95).  Limbs are independent:
+ * with an OpenMP build they are spread over the host cores (OMP_NUM_THREADS / orc_set_threads). */
 void orc_nwt_forward_batch(u64 *a, int logN, int limbs, const u64 *q, const u64 *rp)
 {
     u64 N = (u64)1 << logN;
+#pragma omp parallel for schedule(dynamic, 1)
     for (int l = 0; l < limbs; l++) orc_nwt_forward(a + (u64)l * N, logN, q[l], rp + (u64)l * N);
 }
+
+void orc_nwt_inverse_batch(u64 *a, int logN, int limbs, const u64 *q, const u64 *rp)
+{
+    u64 N = (u64)1 << logN;
+#pragma omp parallel for schedule(dynamic, 1)
+    for (int l = 0; l < limbs; l++) orc_nwt_inverse(a + (u64)l * N, logN, q[l], rp + (u64)l * N);
+}
+
+/* c[l] = (c[l] +) a[l] * b[l] mod q[l] over `limbs` limbs of n words (rfhe_framewk/src/negaclic_ntt.py:126 per limb) */
+void orc_modmul_batch(u64 *c, const u64 *a, const u64 *b, u64 n, int limbs, const u64 *q, int accumulate)
+{
+#pragma omp parallel for schedule(static)
+    for (int l = 0; l < limbs; l++) {
+        if (accumulate) orc_modmul_acc(c + (u64)l * n, a + (u64)l * n, b + (u64)l * n, n, q[l]);
+        else orc_modmul(c + (u64)l * n, a + (u64)l * n, b + (u64)l * n, n, q[l]);
+    }
+}
+
+/* worker threads of the batch helpers above (1 = the scalar port); returns the count in effect */
+#ifdef _OPENMP
+#include <omp.h>
+int orc_set_threads(int n)
+{
+    if (n > 0) omp_set_num_threads(n);
+    return omp_get_max_threads();
+}
+#else
+int orc_set_threads(int n)
+{
+    (void)n;
+    return 1;
+}
+#endif

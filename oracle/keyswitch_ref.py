@@ -1,12 +1,12 @@
-"""CPU restatement of the key-switch composite (TEST INFRASTRUCTURE ONLY).
+"""CPU restatement of the key-switch / rotation / homomorphic-multiply composites (TEST INFRASTRUCTURE ONLY).
 
-The reference has no key-switch source (SEAL/Phantom are absent); what it holds is the
-operation sequence of one KEYSWITCH + MODSWITCH in its SEAL traces
-(profile_framewk/build/data/ckks/16384_4:466-539, summarised by
-profile_framewk/build/sum_trace.py:10-94).  This file states that sequence with the
-oracle's primitives so the GPU composite can be checked word for word; its VALUES have
-no reference counterpart ("parity unpinned" against SEAL), so tests/ also check the
-defining algebraic property (out0 + out1*s ~ c*s') with big integers.
+The reference has no source for these (SEAL/Phantom are absent); what it holds is the operation sequence of
+KEYSWITCH + MODSWITCH, ROTATE, MULTIPLY_CKKS and RELIN in its SEAL traces
+(profile_framewk/build/data/ckks/16384_4:388-539, summarised by profile_framewk/build/sum_trace.py:10-94) and the
+call sequence multiply -> relinearize -> mod_switch -> rotate of reliability_test/dotprod_test.cu:113-115,143-148.
+This file states those sequences with the oracle's pinned primitives (oracle/cport.py) so the GPU composites can be
+checked word for word at any size; their VALUES have no reference counterpart ("parity unpinned" against SEAL), so
+tests/ also check the defining algebraic properties (out0 + out1*s ~ c*s', decrypt(hmult) ~ m1*m2) with big integers.
 """
 import numpy as np
 
@@ -15,50 +15,114 @@ from . import cport as O
 
 def galois_coeff(a, k, q):
     """x -> x^k on a coefficient vector mod (x^N + 1, q)."""
-    N = len(a)
+    a = np.asarray(a, dtype=np.uint64)
+    N = a.size
+    j = (np.arange(N, dtype=np.uint64) * np.uint64(k)) % np.uint64(2 * N)
+    v = a % np.uint64(q)
+    neg = j >= N
     out = np.zeros(N, dtype=np.uint64)
-    for i in range(N):
-        j = (i * k) % (2 * N)
-        v = int(a[i]) % q
-        if j >= N:
-            out[j - N] = (q - v) % q
-        else:
-            out[j] = v
+    out[(j % np.uint64(N)).astype(np.int64)] = np.where(neg, (np.uint64(q) - v) % np.uint64(q), v)
     return out
 
 
-def keyswitch_ref(c, evk, qs, L, K, dnum, logn):
-    """c: (L, N) NTT domain; evk: (dnum, 2, L+K, N) NTT domain; returns (out0, out1), each (L, N)."""
+def _tables(qs, logn):
+    return np.stack([O.root_powers(q, logn) for q in qs])
+
+
+def keyswitch_ref(c, evk, qs, L, K, dnum, logn, add0=None, add1=None, rps=None):
+    """c: (L, N) NTT domain; evk: (dnum, 2, L+K, N) NTT domain; returns (out0, out1), each (L, N).
+    add0 / add1: optional (L, N) terms added to the outputs (rotation: sigma(c0); relinearisation: d0, d1)."""
     M, N = L + K, 1 << logn
     alpha = -(-L // dnum)
-    rps = [O.root_powers(q, logn) for q in qs]
-    coef = [O.nwt_inverse(c[l], qs[l], rps[l]) for l in range(L)]             # INTT of the input limbs
+    qs = [int(q) for q in qs]
+    rps = _tables(qs, logn) if rps is None else rps
+    c = np.asarray(c, dtype=np.uint64)
+    coef = O.nwt_inverse_batch(c, qs[:L], rps[:L])                            # INTT of the input limbs
     acc = np.zeros((2, M, N), dtype=np.uint64)
     for d in range(dnum):
         lo, hi = d * alpha, min(L, (d + 1) * alpha)
         other = [j for j in range(M) if j < lo or j >= hi]
-        conv = O.baseconv_exact(np.stack(coef[lo:hi]), qs[lo:hi], [qs[j] for j in other])   # MODREDUCTION
-        ext = [None] * M
-        for pos, j in enumerate(other):
-            ext[j] = O.nwt_forward(conv[pos], qs[j], rps[j])
-        for j in range(lo, hi):
-            ext[j] = np.asarray(c[j], dtype=np.uint64)
-        for h in range(2):
-            for j in range(M):                                                               # MULTEVALK
-                acc[h, j] = O.modmul_acc(acc[h, j], ext[j], evk[d, h, j], qs[j])
+        conv = O.baseconv_exact(coef[lo:hi], qs[lo:hi], [qs[j] for j in other])               # MODREDUCTION
+        ext = np.zeros((M, N), dtype=np.uint64)
+        ext[other] = O.nwt_forward_batch(conv, [qs[j] for j in other], rps[other])
+        ext[lo:hi] = c[lo:hi]
+        for h in range(2):                                                                     # MULTEVALK
+            acc[h] = O.modmul_batch(ext, evk[d, h], qs, acc=acc[h])
     outs = []
     P, Q = qs[L:], qs[:L]
-    for h in range(2):                                                                       # MODSWITCH
-        tP = np.stack([O.nwt_inverse(acc[h, L + k], P[k], rps[L + k]) for k in range(K)])
-        conv = O.baseconv_exact(tP, P, Q)
+    for h in range(2):                                                                         # MODSWITCH
+        tP = O.nwt_inverse_batch(acc[h, L:], P, rps[L:])
+        cn = O.nwt_forward_batch(O.baseconv_exact(tP, P, Q), Q, rps[:L])
         out = np.zeros((L, N), dtype=np.uint64)
+        add = (add0, add1)[h]
         for j in range(L):
-            cn = O.nwt_forward(conv[j], Q[j], rps[j])
             pm = 1
             for pk in P:
                 pm = pm * (pk % Q[j]) % Q[j]
-            pinv = pow(pm, -1, Q[j])
-            diff = (acc[h, j].astype(object) - cn.astype(object)) % Q[j]
-            out[j] = ((diff * pinv) % Q[j]).astype(np.uint64)
+            pinv = np.full(N, pow(pm, -1, Q[j]), dtype=np.uint64)
+            qj = np.uint64(Q[j])
+            diff = (acc[h, j] + (qj - cn[j])) % qj
+            out[j] = O.modmul(diff, pinv, Q[j])
+            if add is not None:
+                out[j] = (out[j] + np.asarray(add[j], dtype=np.uint64) % qj) % qj
         outs.append(out)
     return outs[0], outs[1]
+
+
+def rotate_ref(c0, c1, k, gk, qs, L, K, dnum, logn):
+    """ROTATE (16384_4:452-539 / rotate_inplace, dotprod_test.cu:146): sigma_k on both parts, key switch of sigma(c1)
+    with the Galois key, plus sigma(c0).  sigma is applied in the coefficient domain here (the engine permutes the
+    NTT-domain slots instead)."""
+    qs = [int(q) for q in qs]
+    rps = _tables(qs, logn)
+
+    def sigma(x):
+        co = O.nwt_inverse_batch(np.asarray(x, dtype=np.uint64), qs[:L], rps[:L])
+        co = np.stack([galois_coeff(co[l], k, qs[l]) for l in range(L)])
+        return O.nwt_forward_batch(co, qs[:L], rps[:L])
+
+    return keyswitch_ref(sigma(c1), gk, qs, L, K, dnum, logn, add0=sigma(c0), rps=rps)
+
+
+def tensor_ref(a0, a1, b0, b1, qs):
+    """MULTIPLY_CKKS (16384_4:388-389 / multiply, dotprod_test.cu:113), NTT domain, per limb."""
+    L = a0.shape[0]
+    qs = [int(q) for q in qs[:L]]
+    d0 = O.modmul_batch(a0, b0, qs)
+    d1 = O.modmul_batch(a1, b0, qs, acc=O.modmul_batch(a0, b1, qs))
+    d2 = O.modmul_batch(a1, b1, qs)
+    return d0, d1, d2
+
+
+def rescale_ref(parts, qs, L, logn, plain_modulus=0):
+    """mod_switch_to_next (dotprod_test.cu:115): parts (n, L, N) NTT domain -> (n, L-1, N);
+    c' = (c - delta) / q_last with delta = [c]_{q_last} (plain_modulus = 0) or t [c t^-1]_{q_last} (BGV)."""
+    qs = [int(q) for q in qs[:L]]
+    ql, N = qs[L - 1], 1 << logn
+    rps = _tables(qs, logn)
+    out = []
+    for c in parts:
+        c = np.asarray(c, dtype=np.uint64)
+        y = O.nwt_inverse(c[L - 1], ql, rps[L - 1])
+        if plain_modulus:
+            y = O.modmul(y, np.full(N, pow(plain_modulus % ql, -1, ql), dtype=np.uint64), ql)
+        delta = np.stack([y % np.uint64(q) for q in qs[:L - 1]])
+        if plain_modulus:
+            delta = np.stack([O.modmul(delta[j], np.full(N, plain_modulus % qs[j], dtype=np.uint64), qs[j]) for j in range(L - 1)])
+        dn = O.nwt_forward_batch(delta, qs[:L - 1], rps[:L - 1])
+        r = np.zeros((L - 1, N), dtype=np.uint64)
+        for j in range(L - 1):
+            qj = np.uint64(qs[j])
+            r[j] = O.modmul((c[j] % qj + (qj - dn[j])) % qj, np.full(N, pow(ql % qs[j], -1, qs[j]), dtype=np.uint64), qs[j])
+        out.append(r)
+    return np.stack(out)
+
+
+def hmult_ref(a0, a1, b0, b1, rlk, qs, L, K, dnum, logn, rescale=True, plain_modulus=0):
+    """multiply -> relinearize -> mod_switch_to_next (dotprod_test.cu:113-115)."""
+    d0, d1, d2 = tensor_ref(a0, a1, b0, b1, qs)
+    c0, c1 = keyswitch_ref(d2, rlk, qs, L, K, dnum, logn, add0=d0, add1=d1)
+    if not rescale:
+        return c0, c1
+    r = rescale_ref([c0, c1], qs, L, logn, plain_modulus)
+    return r[0], r[1]
