@@ -88,6 +88,11 @@ _SIG = {
     "fhe_automorphism_ntt": (ci, [vp, vp, vp, ci, C.c_uint32, sz, vp]),
     "fhe_keyswitch_create": (ci, [vp, vp, ci, ci, ci, C.POINTER(vp)]),
     "fhe_keyswitch_destroy": (ci, [vp]),
+    "fhe_keyswitch_shard_layout": (ci, [ci, ci, ci, ci, C.POINTER(ci)]),
+    "fhe_keyswitch_create_sharded": (ci, [vp, vp, ci, ci, ci, ci, ci, vp, vp, C.POINTER(vp)]),
+    "fhe_keyswitch_shard_begin": (ci, [vp, vp, vp, vp]),
+    "fhe_keyswitch_shard_inner": (ci, [vp, vp, vp, vp, vp]),
+    "fhe_keyswitch_shard_finish": (ci, [vp, vp, vp, vp, vp, vp, vp]),
     "fhe_keyswitch_apply": (ci, [vp, vp, vp, vp, vp, vp, vp]),
     "fhe_rotate": (ci, [vp, vp, vp, vp, vp, vp, C.c_uint32, vp, vp]),
     "fhe_tensor_product": (ci, [vp, vp, vp, vp, vp, vp, vp, vp, vp, sz, sz, vp]),

@@ -286,6 +286,7 @@ __device__ __forceinline__ void bc_exact_body(const BcJob &job, u64 N, u32 oc)
     const u64 *__restrict__ in = job.in;
     u64 *__restrict__ out = job.out;
     const int m = pl.m, k = pl.k;
+    const u32 FHE_CONSTANT *rows = (const u32 FHE_CONSTANT *)(__UINTPTR_TYPE__)job.in_rows;
     // the plan's tables are never written by a kernel: constant address space, so uniform reads become scalar loads
     // whatever the compiler can or cannot prove about `out`
     const Tw FHE_CONSTANT *dig = (const Tw FHE_CONSTANT *)(__UINTPTR_TYPE__)pl.dig, *hor = (const Tw FHE_CONSTANT *)(__UINTPTR_TYPE__)pl.hor;
@@ -318,7 +319,8 @@ __device__ __forceinline__ void bc_exact_body(const BcJob &job, u64 N, u32 oc)
             if (j < m) {
                 const u64 pj = STAGE ? s_pi[j] : mod_in[j];
                 const auto cx = B::ctx(pj, c_fpi(j));
-                T t = B::mul(B::load(in[(u64)j * N + i], pj), c_dig(j, j), cx);
+                const u64 row = rows ? (u64)rows[j] : (u64)j;
+                T t = B::mul(B::load(in[row * N + i], pj), c_dig(j, j), cx);
 #pragma unroll UNR
                 for (int l = 0; l < j; l++) {
                     t = B::sub(t, B::mul(c[l], c_dig(l, j), cx), cx);
@@ -386,14 +388,14 @@ static u32 bc_slices(u32 gx, u32 jobs, int m, int k)
     return slices;
 }
 
-hipError_t launch_baseconv_exact(hipStream_t st, u64 *out, const u64 *in, const BaseConvPlanDev &pl, u64 N, u32 gap_at, u32 gap)
+hipError_t launch_baseconv_exact(hipStream_t st, u64 *out, const u64 *in, const BaseConvPlanDev &pl, u64 N, u32 gap_at, u32 gap, const u32 *in_rows)
 {
     if (pl.m > BC_MAX_LIMBS) return hipErrorInvalidValue;
     u64 want = (N + 255) / 256;
     const u32 gx = (u32)(want > 16384 ? 16384 : want);
     const u32 slices = bc_slices(gx, 1, pl.m, pl.k), oc = ((u32)pl.k + slices - 1) / slices;
     const dim3 grid(gx, ((u32)pl.k + oc - 1) / oc);
-    const BcJob job{pl, in, out, gap_at, gap};
+    const BcJob job{pl, in, out, gap_at, gap, in_rows};
     if (pl.f64) launch_exact<BcF64>(st, grid, nullptr, job, pl.m, N, oc);
     else launch_exact<BcU64>(st, grid, nullptr, job, pl.m, N, oc);
     return hipGetLastError();
@@ -561,9 +563,10 @@ __device__ __forceinline__ void ks_mac_limb(const KsMacArgs &a, u32 j, u64 i, co
 {
     const u64 N = (u64)1 << a.logn;
     typename K::acc_t s0 = K::zero(), s1 = K::zero();
+    const u32 tl = j < a.cn ? a.clo + j : 0xFFFFFFFFu;     // table limb when the row is a ciphertext limb
     for (u32 d = 0; d < a.dnum; d++) {
         const u32 lo = d * a.alpha, hi = lo + a.alpha < a.L ? lo + a.alpha : a.L;
-        const u64 x = (j >= lo && j < hi) ? a.c[(u64)j * N + i] : a.ext[((u64)d * a.M + j) * N + i];
+        const u64 x = (tl >= lo && tl < hi) ? a.c[(u64)j * N + i] : a.ext[((u64)d * a.M + j) * N + i];
         const u64 *key = a.evk + ((u64)d * 2 * a.M + j) * N + i;
         K::mac(s0, x, key[0], (int)d, p);
         K::mac(s1, x, key[(u64)a.M * N], (int)d, p);
@@ -578,7 +581,7 @@ __global__ __launch_bounds__(256) void k_ks_mac(KsMacArgs a)
     for (u64 e = blockIdx.x * (u64)blockDim.x + threadIdx.x; e < total; e += (u64)gridDim.x * blockDim.x) {
         const u32 j = (u32)(e >> a.logn);
         const u64 i = e & (((u64)1 << a.logn) - 1);
-        const LimbParams &p = a.lp[j];
+        const LimbParams &p = a.lp[j < a.cn ? a.clo + j : j + a.sp_shift];
         if (p.path == PATH_F64) ks_mac_limb<KsMacF64>(a, j, i, p);
         else ks_mac_limb<KsMacU64>(a, j, i, p);
     }

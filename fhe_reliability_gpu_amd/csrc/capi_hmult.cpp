@@ -42,6 +42,7 @@ static int rescale_core(fhe_ctx *ctx, fhe_keyswitch *p, uint64_t *const *outs, c
     if (n_parts < 1 || n_parts > 3) return fail(FHE_ERR_INVALID, "a ciphertext has 1 to 3 parts");
     for (size_t i = 0; i < n_parts; i++)
         if (!outs[i]) return fail(FHE_ERR_INVALID, "null argument");
+    if (p->sharded) return fail(FHE_ERR_UNSUPPORTED, "rescale of a limb-sharded ciphertext is not built: gather the last limb on the host side");
     if (p->L < 2 || !p->last) return fail(FHE_ERR_INVALID, "no prime left to drop");
     HIP_TRY(hipSetDevice(ctx->device));
     hipStream_t st = pick(ctx, stream);
@@ -87,6 +88,7 @@ int fhe_hmult(fhe_ctx *ctx, fhe_keyswitch *p, uint64_t *d_out0, uint64_t *d_out1
 {
     if (!ctx || !p || !d_out0 || !d_out1 || !d_relin_key) return fail(FHE_ERR_INVALID, "null argument");
     if (rescale && p->L < 2) return fail(FHE_ERR_INVALID, "no prime left to drop");
+    if (p->sharded) return fail(FHE_ERR_UNSUPPORTED, "fhe_hmult runs on one device; sharded jobs use fhe_tensor_product + the fhe_keyswitch_shard_* phases");
     const size_t N = (size_t)1 << p->log_n, L = p->L;
     u64 *d0 = p->hm.as<u64>(), *d1 = d0 + L * N, *d2 = d1 + L * N, *pre = p->hm_pre.as<u64>();
     int rc;

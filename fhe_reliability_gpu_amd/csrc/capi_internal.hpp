@@ -122,16 +122,32 @@ struct fhe_abft {
     DevBuf sum_in, sum_out;     // scratch checksums (grown on demand)
 };
 
+// Which limbs a rank of a limb-sharded key switch owns: ciphertext limbs [clo, clo + cn) and special limbs
+// [slo, slo + sn) (table indices, slo >= L); cmax / smax = the largest slab of any rank (rows per rank in the two
+// gather buffers).  world = 1: everything.
+struct KsShard {
+    int world = 1, rank = 0, clo = 0, cn = 0, slo = 0, sn = 0, cmax = 0, smax = 0;
+};
+void ks_shard_layout(int L, int K, int world, int rank, KsShard *s);
+
 struct fhe_keyswitch {
     fhe_ctx *ctx = nullptr;
     const fhe_ntt_tables *t = nullptr;
     int L = 0, K = 0, dnum = 0, alpha = 0, log_n = 0;
+    KsShard sh;                         // owned limbs (capi_keyswitch.cpp)
+    bool sharded = false;               // caller-owned gather buffers + the three phases (always when world > 1)
+    int m_own = 0;                      // cn + sn: rows of ext / acc / the key on this rank
+    u64 *g1 = nullptr, *g2 = nullptr;   // gather buffers: [world][cmax][N] coefficient-form input, [world][2][smax][N] special limbs
+    DevBuf up_rows, down_rows;          // row of each conversion input limb inside g1 / g2 (or acc on one device)
+    bool up_f64 = false;
+    u32 n_up_jobs = 0;
+    std::vector<BcJob> up_host;         // host copy of the digit jobs (mixed arithmetic paths: one launch per digit)
     u64 plain_modulus = 0;              // BGV: delta must vanish modulo this (0 = CKKS-style flooring)
     std::vector<u64> t_inv_P, t_mod_Q;  // plain_modulus^-1 mod p_k, plain_modulus mod q_j
-    std::vector<fhe_baseconv *> up;     // per digit: digit primes -> every other prime (ascending index)
-    fhe_baseconv *down = nullptr;       // P -> Q
-    DevBuf pinv;                        // P^-1 mod q_j, j < L
-    DevBuf coef, ext, acc, conv, rot;  // coef [L][N], ext [dnum][M][N], acc [2][M][N], conv [2][L][N]
+    std::vector<fhe_baseconv *> up;     // per digit: digit primes -> every other owned prime (ascending row; nullptr: nothing to extend to)
+    fhe_baseconv *down = nullptr;       // P -> owned ciphertext primes
+    DevBuf pinv;                        // P^-1 mod q_j, owned j
+    DevBuf coef, ext, acc, conv, rot;  // coef [L][N] (one device: = g1), ext [dnum][m_own][N], acc [2][m_own][N], conv [2][cn][N]
     DevBuf up_jobs, down_jobs;         // device job lists: all digit extensions / both mod-down conversions in one launch each
     int up_max_m = 0, up_max_k = 0;
     bool up_batched = false;           // every digit plan on the same arithmetic path

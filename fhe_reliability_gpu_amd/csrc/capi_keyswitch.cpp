@@ -1,5 +1,311 @@
 // capi_keyswitch.cpp -- Galois automorphisms, hybrid key switching, rotation (part of the C ABI of include/fhe_mi355x.h; shared pieces in capi_internal.hpp)
+//
+// One plan type serves a single device and a rank of a limb-sharded job (BASELINE configs 4-5: "RNS limbs sharded across
+// 8 x MI355X + RCCL all-gather"): a rank OWNS a slab of the L ciphertext primes and a slab of the K special primes
+// (ks_shard_layout), keeps its limbs of the input, of every key digit and of the result, and runs
+//   begin  : INTT of the owned ciphertext limbs into its slot of gather buffer 1            -> all-gather 1 (host, RCCL)
+//   inner  : per digit exact extension to the owned limbs, NTT, inner product with the key,
+//            INTT of the owned special limbs into its slot of gather buffer 2                -> all-gather 2
+//   finish : mod-down to the owned ciphertext limbs
+// With world = 1 the owner has everything, the slots are the whole buffers and fhe_keyswitch_apply runs the three
+// phases back to back with no collective.
 #include "capi_internal.hpp"
+
+void ks_shard_layout(int L, int K, int world, int rank, KsShard *s)
+{
+    s->world = world;
+    s->rank = rank;
+    const int cb = L / world, ce = L % world;
+    s->clo = rank * cb + std::min(rank, ce);
+    s->cn = cb + (rank < ce ? 1 : 0);
+    s->cmax = cb + (ce ? 1 : 0);
+    // special limbs are handed out from the last rank backwards: the ranks with the smaller ciphertext slabs get them first
+    const int rr = world - 1 - rank, sb = K / world, se = K % world;
+    s->slo = L + rr * sb + std::min(rr, se);
+    s->sn = sb + (rr < se ? 1 : 0);
+    s->smax = sb + (se ? 1 : 0);
+}
+
+// row of ciphertext limb l in gather buffer 1 ([world][cmax][N]) / of special limb k (0-based in P), half h, in gather buffer 2 ([world][2][smax][N])
+static u32 g1_row(int L, int K, int world, int l)
+{
+    for (int r = 0; r < world; r++) {
+        KsShard s;
+        ks_shard_layout(L, K, world, r, &s);
+        if (l >= s.clo && l < s.clo + s.cn) return (u32)(r * s.cmax + (l - s.clo));
+    }
+    return 0;
+}
+static u32 g2_row(int L, int K, int world, int k, int h)
+{
+    for (int r = 0; r < world; r++) {
+        KsShard s;
+        ks_shard_layout(L, K, world, r, &s);
+        if (L + k >= s.slo && L + k < s.slo + s.sn) return (u32)((r * 2 + h) * s.smax + (L + k - s.slo));
+    }
+    return 0;
+}
+
+static int ks_create(fhe_ctx *ctx, const fhe_ntt_tables *t, int L, int K, int dnum, int world, int rank, uint64_t *d_gather1,
+                     uint64_t *d_gather2, fhe_keyswitch **out)
+{
+    if (!ctx || !t || !out || L < 1 || K < 1 || dnum < 1 || dnum > L || L + K > t->count)
+        return fail(FHE_ERR_INVALID, "bad key-switch shape");
+    if (world < 1 || rank < 0 || rank >= world) return fail(FHE_ERR_INVALID, "bad world / rank");
+    if (world > 1 && (!d_gather1 || !d_gather2)) return fail(FHE_ERR_INVALID, "a sharded plan needs the two gather buffers");
+    const bool sharded = d_gather1 && d_gather2;      // world = 1 with buffers: the phase path with (trivial) gathers, as a 1-rank job runs it
+    std::unique_ptr<fhe_keyswitch> p(new fhe_keyswitch);
+    p->ctx = ctx;
+    p->t = t;
+    p->L = L;
+    p->K = K;
+    p->dnum = dnum;
+    p->alpha = (L + dnum - 1) / dnum;
+    p->log_n = t->log_n;
+    p->sharded = sharded;
+    ks_shard_layout(L, K, world, rank, &p->sh);
+    const KsShard &sh = p->sh;
+    const size_t N = (size_t)1 << t->log_n, MO = (size_t)sh.cn + sh.sn;   // owned limbs: rows of ext / acc / the key
+    p->m_own = (int)MO;
+    auto limb_of = [&](size_t jj) { return jj < (size_t)sh.cn ? (size_t)sh.clo + jj : (size_t)sh.slo + (jj - sh.cn); };
+    HIP_TRY(hipSetDevice(ctx->device));
+    // per digit: where the digit's limbs sit in gather buffer 1, which owned rows it skips, and the conversion to the rest
+    std::vector<u32> up_rows((size_t)dnum * p->alpha, 0);
+    std::vector<std::pair<u32, u32>> gaps(dnum);
+    for (int d = 0; d < dnum; d++) {
+        const int lo = d * p->alpha, hi = std::min(L, lo + p->alpha);
+        if (lo >= hi) return fail(FHE_ERR_INVALID, "dnum leaves an empty digit");
+        for (int l = lo; l < hi; l++) up_rows[(size_t)d * p->alpha + (l - lo)] = g1_row(L, K, world, l);
+        const int ga = std::max(lo, sh.clo) - sh.clo, gb = std::min(hi, sh.clo + sh.cn) - sh.clo;     // owned rows inside the digit
+        gaps[d] = gb > ga ? std::make_pair((u32)ga, (u32)(gb - ga)) : std::make_pair(0xFFFFFFFFu, 0u);
+        std::vector<u64> in(t->q.begin() + lo, t->q.begin() + hi), other;
+        for (size_t jj = 0; jj < MO; jj++) {
+            const size_t tl = limb_of(jj);
+            if ((int)tl < lo || (int)tl >= hi) other.push_back(t->q[tl]);
+        }
+        fhe_baseconv *bc = nullptr;
+        if (!other.empty()) {
+            int rc = fhe_baseconv_create(ctx, in.data(), (int)in.size(), other.data(), (int)other.size(), &bc);
+            if (rc) return rc;
+        }
+        p->up.push_back(bc);
+    }
+    if (sh.cn > 0) {
+        std::vector<u64> P(t->q.begin() + L, t->q.begin() + L + K), Q(t->q.begin() + sh.clo, t->q.begin() + sh.clo + sh.cn);
+        int rc = fhe_baseconv_create(ctx, P.data(), K, Q.data(), sh.cn, &p->down);
+        if (rc) return rc;
+        std::vector<u64> pinv(sh.cn);
+        for (int j = 0; j < sh.cn; j++) {
+            u64 pm = 1 % Q[j];
+            for (u64 pk : P) pm = host::mul_mod(pm, pk % Q[j], Q[j]);
+            pinv[j] = host::inv_mod(pm, Q[j]);
+            if (!pinv[j]) return fail(FHE_ERR_INVALID, "special primes must be coprime to the ciphertext primes");
+        }
+        HIP_TRY(p->pinv.upload(pinv));
+    }
+    // every owned limb of every digit's extension except the digit's own limbs, one list per arithmetic path
+    for (int path = 0; path < 2; path++) {
+        std::vector<UnitRef> map;
+        for (int d = 0; d < dnum; d++) {
+            const int lo = d * p->alpha, hi = std::min(L, lo + p->alpha);
+            for (size_t jj = 0; jj < MO; jj++) {
+                const size_t tl = limb_of(jj);
+                if (((int)tl < lo || (int)tl >= hi) && t->path[tl] == path) map.push_back(UnitRef{(u32)(d * MO + jj), (u32)tl});
+            }
+        }
+        p->ext_units[path] = (u32)map.size();
+        if (!map.empty()) HIP_TRY(p->ext_map[path].upload(map));
+    }
+    if (!sharded) {
+        HIP_TRY(p->coef.alloc((size_t)L * N * 8));
+        p->g1 = p->coef.as<u64>();
+        p->g2 = nullptr;   // the special limbs are converted where they stand, inside acc
+    } else {
+        p->g1 = d_gather1;
+        p->g2 = d_gather2;
+    }
+    HIP_TRY(p->ext.alloc((size_t)dnum * MO * N * 8));
+    HIP_TRY(p->acc.alloc(2 * MO * N * 8));
+    HIP_TRY(p->conv.alloc(2 * (size_t)sh.cn * N * 8));
+    HIP_TRY(p->rot.alloc(3 * (size_t)sh.cn * N * 8));
+    HIP_TRY(p->up_rows.upload(up_rows));
+    {
+        std::vector<u32> down_rows((size_t)2 * K);
+        for (int h = 0; h < 2; h++)
+            for (int k = 0; k < K; k++) down_rows[(size_t)h * K + k] = !sharded ? (u32)(h * MO + L + k) : g2_row(L, K, world, k, h);
+        HIP_TRY(p->down_rows.upload(down_rows));
+        std::vector<BcJob> up, down;
+        p->up_batched = true;
+        int first = -1;
+        for (int d = 0; d < dnum; d++) {
+            if (!p->up[d]) continue;
+            const BaseConvPlanDev &pl = p->up[d]->dev;
+            if (first < 0) first = d;
+            up.push_back(BcJob{pl, p->g1, p->ext.as<u64>() + (size_t)d * MO * N, gaps[d].first, gaps[d].second, p->up_rows.as<u32>() + (size_t)d * p->alpha});
+            p->up_max_m = std::max(p->up_max_m, pl.m);
+            p->up_max_k = std::max(p->up_max_k, pl.k);
+            p->up_batched = p->up_batched && pl.f64 == p->up[first]->dev.f64;
+        }
+        p->up_f64 = first >= 0 && p->up[first]->dev.f64 != 0;
+        p->n_up_jobs = (u32)up.size();
+        if (p->down)
+            for (int h = 0; h < 2; h++)
+                down.push_back(BcJob{p->down->dev, !sharded ? p->acc.as<u64>() : p->g2, p->conv.as<u64>() + (size_t)h * sh.cn * N, 0xFFFFFFFFu, 0u,
+                                     p->down_rows.as<u32>() + (size_t)h * K});
+        if (!up.empty()) HIP_TRY(p->up_jobs.upload(up));
+        if (!down.empty()) HIP_TRY(p->down_jobs.upload(down));
+        p->up_host = up;
+    }
+    if (!sharded) {
+        HIP_TRY(p->hm.alloc(3 * (size_t)L * N * 8));
+        HIP_TRY(p->hm_pre.alloc(2 * (size_t)L * N * 8));
+    }
+    if (L >= 2 && !sharded) {
+        // rescale / mod-switch to the next level: drop q_{L-1}
+        const u64 ql = t->q[L - 1];
+        int rc = fhe_baseconv_create(ctx, &ql, 1, t->q.data(), L - 1, &p->last);
+        if (rc) return rc;
+        std::vector<u64> qinv(L - 1);
+        for (int j = 0; j + 1 < L; j++) {
+            qinv[j] = host::inv_mod(ql % t->q[j], t->q[j]);
+            if (!qinv[j]) return fail(FHE_ERR_INVALID, "ciphertext primes must be pairwise coprime");
+        }
+        HIP_TRY(p->qlast_inv.upload(qinv));
+        HIP_TRY(p->rs_last.alloc(3 * N * 8));
+        HIP_TRY(p->rs_delta.alloc(3 * (size_t)(L - 1) * N * 8));
+        std::vector<BcJob> jobs;
+        for (int part = 0; part < 3; part++)
+            jobs.push_back(BcJob{p->last->dev, p->rs_last.as<u64>() + (size_t)part * N, p->rs_delta.as<u64>() + (size_t)part * (L - 1) * N, 0xFFFFFFFFu, 0u});
+        HIP_TRY(p->rs_jobs.upload(jobs));
+    }
+    *out = p.release();
+    return FHE_OK;
+}
+
+// ---------------------------------------------------------------- the phases
+// INTT of the owned ciphertext limbs (the "3 INTT" that open KEYSWITCH in the L = 4 trace, 16384_4:468-470) into this
+// rank's slot of gather buffer 1
+static int ks_begin(fhe_ctx *ctx, fhe_keyswitch *p, const uint64_t *d_c, hipStream_t st)
+{
+    const KsShard &sh = p->sh;
+    if (!sh.cn) return FHE_OK;
+    const size_t N = (size_t)1 << p->log_n;
+    u64 *slot = p->g1 + (size_t)sh.rank * sh.cmax * N;
+    HIP_TRY(hipMemcpyAsync(slot, d_c, (size_t)sh.cn * N * 8, hipMemcpyDeviceToDevice, st));
+    return ntt_batch(ctx, slot, p->t, 1, sh.cn, sh.clo, st, true);
+}
+
+// base extension of each digit to every other owned prime (MODREDUCTION, 16384_4:471-452), their transforms, and the inner
+// product with the key (MULTEVK)
+static int ks_extend_mac(fhe_ctx *ctx, fhe_keyswitch *p, const uint64_t *d_c, const uint64_t *d_evk, hipStream_t st)
+{
+    const fhe_ntt_tables *t = p->t;
+    const KsShard &sh = p->sh;
+    const size_t N = (size_t)1 << p->log_n, MO = p->m_own;
+    const LimbParams *lp = t->d_lp.as<LimbParams>();
+    u64 *ext = p->ext.as<u64>(), *acc = p->acc.as<u64>();
+    hipError_t e;
+    if (!MO) return FHE_OK;
+    {
+        // (one trace line for the phase; the nested NTT line precedes it, as the reference's tools expect of nested costs)
+        TraceScope tr_mr(ctx, st, "MODREDUCTION");
+        if (p->up_batched) {
+            e = launch_baseconv_exact_jobs(st, p->up_jobs.as<BcJob>(), p->n_up_jobs, p->up_max_m, p->up_max_k, p->up_f64, N);
+            if (e != hipSuccess) return hip_fail(e, "launch_baseconv_exact_jobs");
+        } else {
+            for (const BcJob &j : p->up_host) {
+                e = launch_baseconv_exact(st, j.out, j.in, j.pl, N, j.gap_at, j.gap, j.in_rows);
+                if (e != hipSuccess) return hip_fail(e, "launch_baseconv_exact");
+            }
+        }
+        TraceScope tr_ntt(ctx, st, "NTT");
+        for (int path = 0; path < 2; path++) {
+            if (!p->ext_units[path]) continue;
+            PassArgs a{ext, lp, 0u, 1u, p->ext_units[path], 1u, p->ext_map[path].as<UnitRef>()};
+            if ((e = launch_ntt(st, a, p->log_n, false, path, 1)) != hipSuccess) return hip_fail(e, "launch_ntt");
+        }
+    }
+    // multiply-accumulate with the evaluation key (MULTEVK): all digits, both halves, one launch
+    TraceScope tr_mk(ctx, st, "MULTEVK");
+    const KsMacArgs ka{acc, ext, d_c, d_evk, lp, (u32)p->L, (u32)MO, (u32)p->dnum, (u32)p->alpha, p->log_n, (u32)sh.cn, (u32)sh.clo, (u32)(sh.slo - sh.cn)};
+    if ((e = launch_ks_mac(st, ka)) != hipSuccess) return hip_fail(e, "launch_ks_mac");
+    return FHE_OK;
+}
+
+// opening of the mod-down (MODSWITCH, 16384_4:454-463): the owned special limbs of both halves to coefficient form -- in
+// place inside acc ([2][MO][N]) on one device, in this rank's slot of gather buffer 2 ([2][smax][N]) when sharded
+static int ks_special_intt(fhe_ctx *ctx, fhe_keyswitch *p, hipStream_t st)
+{
+    const fhe_ntt_tables *t = p->t;
+    const KsShard &sh = p->sh;
+    if (!sh.sn) return FHE_OK;
+    const size_t N = (size_t)1 << p->log_n, MO = p->m_own;
+    const LimbParams *lp = t->d_lp.as<LimbParams>();
+    u64 *acc = p->acc.as<u64>(), *sp = acc + (size_t)sh.cn * N;
+    u32 stride = (u32)MO;
+    int rc;
+    if (p->sharded) {
+        sp = p->g2 + (size_t)sh.rank * 2 * sh.smax * N;
+        stride = (u32)sh.smax;
+        HIP_TRY(hipMemcpy2DAsync(sp, (size_t)sh.smax * N * 8, acc + (size_t)sh.cn * N, MO * N * 8, (size_t)sh.sn * N * 8, 2, hipMemcpyDeviceToDevice, st));
+    }
+    {
+        TraceScope tr_ntt(ctx, st, "NTT");
+        rc = for_each_run(t, sh.sn, sh.slo, [&](size_t off, size_t len, int path) -> int {
+            PassArgs a{sp + off * N, lp, (u32)(sh.slo + off), (u32)len, (u32)(2 * len), stride, nullptr};
+            hipError_t e2 = launch_ntt(st, a, p->log_n, true, path, 1);
+            return e2 == hipSuccess ? FHE_OK : hip_fail(e2, "launch_ntt");
+        });
+        if (rc) return rc;
+    }
+    // BGV: remove delta = t * [acc * t^-1]_P instead of [acc]_P, so that delta = 0 mod t
+    if (p->plain_modulus)
+        for (int h = 0; h < 2; h++)
+            if ((rc = fhe_scalar_affine(ctx, sp + (size_t)h * stride * N, sp + (size_t)h * stride * N, p->t_inv_P.data() + (sh.slo - p->L), nullptr, t, 1, sh.sn,
+                                        sh.slo, st)))
+                return rc;
+    return FHE_OK;
+}
+
+// rest of the mod-down, to the owned ciphertext limbs: conversion of the (gathered) special limbs to Q, NTT, subtract, times P^-1
+static int ks_finish(fhe_ctx *ctx, fhe_keyswitch *p, uint64_t *d_out0, uint64_t *d_out1, const uint64_t *d_add0, const uint64_t *d_add1,
+                     hipStream_t st)
+{
+    const fhe_ntt_tables *t = p->t;
+    const KsShard &sh = p->sh;
+    if (!sh.cn) return FHE_OK;
+    const size_t N = (size_t)1 << p->log_n, MO = p->m_own;
+    const LimbParams *lp = t->d_lp.as<LimbParams>();
+    u64 *acc = p->acc.as<u64>(), *conv = p->conv.as<u64>();
+    int rc;
+    hipError_t e = launch_baseconv_exact_jobs(st, p->down_jobs.as<BcJob>(), 2, p->down->dev.m, p->down->dev.k, p->down->dev.f64 != 0, N);
+    if (e != hipSuccess) return hip_fail(e, "launch_baseconv_exact_jobs");
+    if (p->plain_modulus && (rc = fhe_scalar_affine(ctx, conv, conv, p->t_mod_Q.data() + sh.clo, nullptr, t, 2, sh.cn, sh.clo, st))) return rc;
+    if ((rc = ntt_batch(ctx, conv, t, 2, sh.cn, sh.clo, st, false))) return rc;
+    const SubScaleArgs sa{d_out0, d_out1, acc, conv, d_add0, p->pinv.as<u64>(), (u64)(MO * N), (u64)((size_t)sh.cn * N), lp, (u32)sh.clo, (u32)sh.cn, p->log_n, d_add1};
+    if ((e = launch_sub_scale(st, sa)) != hipSuccess) return hip_fail(e, "launch_sub_scale");
+    return FHE_OK;
+}
+
+// Hybrid RNS key switching on one device, operation order of the reference's SEAL trace (profile_framewk/build/data/ckks/16384_4:466-539)
+// with the launches batched.  d_add0 / d_add1 (optional, L x N): added to the output parts -- a rotation passes sigma(c0), a
+// relinearisation d0 and d1.
+int keyswitch_core(fhe_ctx *ctx, fhe_keyswitch *p, uint64_t *d_out0, uint64_t *d_out1, const uint64_t *d_c, const uint64_t *d_evk,
+                   const uint64_t *d_add0, const uint64_t *d_add1, void *stream)
+{
+    if (!ctx || !p || !d_out0 || !d_out1 || !d_c || !d_evk) return fail(FHE_ERR_INVALID, "null argument");
+    if (p->sharded)
+        return fail(FHE_ERR_INVALID, "a sharded plan runs through fhe_keyswitch_shard_begin / _inner / _finish with the all-gathers between them");
+    HIP_TRY(hipSetDevice(ctx->device));
+    hipStream_t st = pick(ctx, stream);
+    int rc;
+    TraceScope tr_ks(ctx, st, "KEYSWITCH");
+    if ((rc = ks_begin(ctx, p, d_c, st))) return rc;
+    if ((rc = ks_extend_mac(ctx, p, d_c, d_evk, st))) return rc;
+    TraceScope tr_ms(ctx, st, "MODSWITCH");
+    if ((rc = ks_special_intt(ctx, p, st))) return rc;
+    return ks_finish(ctx, p, d_out0, d_out1, d_add0, d_add1, st);
+}
 
 extern "C" {
 
@@ -30,95 +336,26 @@ int fhe_automorphism_ntt(fhe_ctx *ctx, uint64_t *d_dst, const uint64_t *d_src, i
 
 int fhe_keyswitch_create(fhe_ctx *ctx, const fhe_ntt_tables *t, int L, int K, int dnum, fhe_keyswitch **out)
 {
-    if (!ctx || !t || !out || L < 1 || K < 1 || dnum < 1 || dnum > L || L + K > t->count)
-        return fail(FHE_ERR_INVALID, "bad key-switch shape");
-    std::unique_ptr<fhe_keyswitch> p(new fhe_keyswitch);
-    p->ctx = ctx;
-    p->t = t;
-    p->L = L;
-    p->K = K;
-    p->dnum = dnum;
-    p->alpha = (L + dnum - 1) / dnum;
-    p->log_n = t->log_n;
-    const size_t N = (size_t)1 << t->log_n, M = (size_t)L + K;
-    for (int d = 0; d < dnum; d++) {
-        const int lo = d * p->alpha, hi = std::min(L, lo + p->alpha);
-        if (lo >= hi) return fail(FHE_ERR_INVALID, "dnum leaves an empty digit");
-        std::vector<u64> in(t->q.begin() + lo, t->q.begin() + hi), other;
-        for (size_t j = 0; j < M; j++)
-            if ((int)j < lo || (int)j >= hi) other.push_back(t->q[j]);
-        fhe_baseconv *bc = nullptr;
-        int rc = fhe_baseconv_create(ctx, in.data(), (int)in.size(), other.data(), (int)other.size(), &bc);
-        if (rc) return rc;
-        p->up.push_back(bc);
-    }
-    {
-        std::vector<u64> P(t->q.begin() + L, t->q.begin() + M), Q(t->q.begin(), t->q.begin() + L);
-        int rc = fhe_baseconv_create(ctx, P.data(), K, Q.data(), L, &p->down);
-        if (rc) return rc;
-        std::vector<u64> pinv(L);
-        for (int j = 0; j < L; j++) {
-            u64 pm = 1 % Q[j];
-            for (u64 pk : P) pm = host::mul_mod(pm, pk % Q[j], Q[j]);
-            pinv[j] = host::inv_mod(pm, Q[j]);
-            if (!pinv[j]) return fail(FHE_ERR_INVALID, "special primes must be coprime to the ciphertext primes");
-        }
-        HIP_TRY(hipSetDevice(ctx->device));
-        HIP_TRY(p->pinv.upload(pinv));
-    }
-    // every limb of every digit's extension except the digit's own limbs, one list per arithmetic path
-    for (int path = 0; path < 2; path++) {
-        std::vector<UnitRef> map;
-        for (int d = 0; d < dnum; d++) {
-            const int lo = d * p->alpha, hi = std::min(L, lo + p->alpha);
-            for (size_t j = 0; j < M; j++)
-                if (((int)j < lo || (int)j >= hi) && t->path[j] == path) map.push_back(UnitRef{(u32)(d * M + j), (u32)j});
-        }
-        p->ext_units[path] = (u32)map.size();
-        if (!map.empty()) HIP_TRY(p->ext_map[path].upload(map));
-    }
-    HIP_TRY(p->coef.alloc(L * N * 8));
-    HIP_TRY(p->ext.alloc((size_t)dnum * M * N * 8));
-    HIP_TRY(p->acc.alloc(2 * M * N * 8));
-    HIP_TRY(p->conv.alloc(2 * (size_t)L * N * 8));
-    HIP_TRY(p->rot.alloc(3 * (size_t)L * N * 8));
-    {
-        std::vector<BcJob> up, down;
-        p->up_batched = true;
-        for (int d = 0; d < dnum; d++) {
-            const size_t lo = (size_t)d * p->alpha, hi = std::min((size_t)L, lo + (size_t)p->alpha);
-            const BaseConvPlanDev &pl = p->up[d]->dev;
-            up.push_back(BcJob{pl, p->coef.as<u64>() + lo * N, p->ext.as<u64>() + (size_t)d * M * N, (u32)lo, (u32)(hi - lo)});
-            p->up_max_m = std::max(p->up_max_m, pl.m);
-            p->up_max_k = std::max(p->up_max_k, pl.k);
-            p->up_batched = p->up_batched && pl.f64 == p->up[0]->dev.f64;
-        }
-        for (int h = 0; h < 2; h++)
-            down.push_back(BcJob{p->down->dev, p->acc.as<u64>() + ((size_t)h * M + L) * N, p->conv.as<u64>() + (size_t)h * L * N, 0xFFFFFFFFu, 0u});
-        HIP_TRY(p->up_jobs.upload(up));
-        HIP_TRY(p->down_jobs.upload(down));
-    }
-    HIP_TRY(p->hm.alloc(3 * (size_t)L * N * 8));
-    HIP_TRY(p->hm_pre.alloc(2 * (size_t)L * N * 8));
-    if (L >= 2) {
-        // rescale / mod-switch to the next level: drop q_{L-1}
-        const u64 ql = t->q[L - 1];
-        int rc = fhe_baseconv_create(ctx, &ql, 1, t->q.data(), L - 1, &p->last);
-        if (rc) return rc;
-        std::vector<u64> qinv(L - 1);
-        for (int j = 0; j + 1 < L; j++) {
-            qinv[j] = host::inv_mod(ql % t->q[j], t->q[j]);
-            if (!qinv[j]) return fail(FHE_ERR_INVALID, "ciphertext primes must be pairwise coprime");
-        }
-        HIP_TRY(p->qlast_inv.upload(qinv));
-        HIP_TRY(p->rs_last.alloc(3 * N * 8));
-        HIP_TRY(p->rs_delta.alloc(3 * (size_t)(L - 1) * N * 8));
-        std::vector<BcJob> jobs;
-        for (int part = 0; part < 3; part++)
-            jobs.push_back(BcJob{p->last->dev, p->rs_last.as<u64>() + (size_t)part * N, p->rs_delta.as<u64>() + (size_t)part * (L - 1) * N, 0xFFFFFFFFu, 0u});
-        HIP_TRY(p->rs_jobs.upload(jobs));
-    }
-    *out = p.release();
+    return ks_create(ctx, t, L, K, dnum, 1, 0, nullptr, nullptr, out);
+}
+
+int fhe_keyswitch_create_sharded(fhe_ctx *ctx, const fhe_ntt_tables *t, int L, int K, int dnum, int world, int rank, uint64_t *d_gather1,
+                                 uint64_t *d_gather2, fhe_keyswitch **out)
+{
+    return ks_create(ctx, t, L, K, dnum, world, rank, d_gather1, d_gather2, out);
+}
+
+int fhe_keyswitch_shard_layout(int L, int K, int world, int rank, int out[6])
+{
+    if (!out || L < 1 || K < 1 || world < 1 || rank < 0 || rank >= world) return fail(FHE_ERR_INVALID, "bad shard arguments");
+    KsShard s;
+    ks_shard_layout(L, K, world, rank, &s);
+    out[0] = s.clo;
+    out[1] = s.cn;
+    out[2] = s.slo;
+    out[3] = s.sn;
+    out[4] = s.cmax;
+    out[5] = s.smax;
     return FHE_OK;
 }
 
@@ -153,89 +390,35 @@ int fhe_keyswitch_destroy(fhe_keyswitch *p)
     return FHE_OK;
 }
 
-// Hybrid RNS key switching, operation order of the reference's SEAL trace (profile_framewk/build/data/ckks/16384_4:466-539)
-// with the launches batched: one INTT, one base extension per digit written straight into the [dnum][M][N]
-// layout, ONE forward transform over every extended limb of every digit (unit list), ONE inner-product launch
-// for all digits and both key halves, and a mod-down that handles both halves per launch where the layout allows.
 int fhe_keyswitch_apply(fhe_ctx *ctx, fhe_keyswitch *p, uint64_t *d_out0, uint64_t *d_out1, const uint64_t *d_c,
                         const uint64_t *d_evk, void *stream)
 {
     return keyswitch_core(ctx, p, d_out0, d_out1, d_c, d_evk, nullptr, nullptr, stream);
 }
 
-} // extern "C"
-
-// d_add0 / d_add1 (optional, L x N): added to the output parts -- a rotation passes sigma(c0), a relinearisation d0 and d1
-int keyswitch_core(fhe_ctx *ctx, fhe_keyswitch *p, uint64_t *d_out0, uint64_t *d_out1, const uint64_t *d_c, const uint64_t *d_evk,
-                   const uint64_t *d_add0, const uint64_t *d_add1, void *stream)
+int fhe_keyswitch_shard_begin(fhe_ctx *ctx, fhe_keyswitch *p, const uint64_t *d_c_local, void *stream)
 {
-    if (!ctx || !p || !d_out0 || !d_out1 || !d_c || !d_evk) return fail(FHE_ERR_INVALID, "null argument");
+    if (!ctx || !p || (!d_c_local && p->sh.cn)) return fail(FHE_ERR_INVALID, "null argument");
     HIP_TRY(hipSetDevice(ctx->device));
-    hipStream_t st = pick(ctx, stream);
-    const fhe_ntt_tables *t = p->t;
-    const size_t N = (size_t)1 << p->log_n, L = p->L, K = p->K, M = L + K;
-    const LimbParams *lp = t->d_lp.as<LimbParams>();
-    u64 *coef = p->coef.as<u64>(), *ext = p->ext.as<u64>(), *acc = p->acc.as<u64>(), *conv = p->conv.as<u64>();
-    int rc;
-    hipError_t e;
-    TraceScope tr_ks(ctx, st, "KEYSWITCH");
-    // INTT of the L input limbs (the "3 INTT" that open KEYSWITCH in the L=4 trace, 16384_4:468-470)
-    HIP_TRY(hipMemcpyAsync(coef, d_c, L * N * 8, hipMemcpyDeviceToDevice, st));
-    if ((rc = ntt_batch(ctx, coef, t, 1, L, 0, st, true))) return rc;
-    {
-        // base extension of each digit to every other prime (MODREDUCTION, 16384_4:471-452), then their transforms
-        // (one trace line for the phase; the nested NTT line precedes it, as the reference's tools expect of nested costs)
-        TraceScope tr_mr(ctx, st, "MODREDUCTION");
-        if (p->up_batched) {
-            e = launch_baseconv_exact_jobs(st, p->up_jobs.as<BcJob>(), (u32)p->dnum, p->up_max_m, p->up_max_k, p->up[0]->dev.f64 != 0, N);
-            if (e != hipSuccess) return hip_fail(e, "launch_baseconv_exact_jobs");
-        } else {
-            for (int d = 0; d < p->dnum; d++) {
-                const size_t lo = (size_t)d * p->alpha, hi = std::min(L, lo + (size_t)p->alpha);
-                e = launch_baseconv_exact(st, ext + (size_t)d * M * N, coef + lo * N, p->up[d]->dev, N, (u32)lo, (u32)(hi - lo));
-                if (e != hipSuccess) return hip_fail(e, "launch_baseconv_exact");
-            }
-        }
-        TraceScope tr_ntt(ctx, st, "NTT");
-        for (int path = 0; path < 2; path++) {
-            if (!p->ext_units[path]) continue;
-            PassArgs a{ext, lp, 0u, 1u, p->ext_units[path], 1u, p->ext_map[path].as<UnitRef>()};
-            if ((e = launch_ntt(st, a, p->log_n, false, path, 1)) != hipSuccess) return hip_fail(e, "launch_ntt");
-        }
-    }
-    {
-        // multiply-accumulate with the evaluation key (MULTEVK): all digits, both halves, one launch
-        TraceScope tr_mk(ctx, st, "MULTEVK");
-        const KsMacArgs ka{acc, ext, d_c, d_evk, lp, (u32)L, (u32)M, (u32)p->dnum, (u32)p->alpha, p->log_n};
-        if ((e = launch_ks_mac(st, ka)) != hipSuccess) return hip_fail(e, "launch_ks_mac");
-    }
-    // mod-down by P (MODSWITCH, 16384_4:454-463): INTT of the special limbs, conversion to Q, NTT, subtract, times P^-1
-    TraceScope tr_ms(ctx, st, "MODSWITCH");
-    {
-        // the K special limbs of both halves, in place inside acc ([2][M][N], polynomial stride M)
-        TraceScope tr_ntt(ctx, st, "NTT");
-        rc = for_each_run(t, K, L, [&](size_t off, size_t len, int path) -> int {
-            PassArgs a{acc + (L + off) * N, lp, (u32)(L + off), (u32)len, (u32)(2 * len), (u32)M, nullptr};
-            hipError_t e2 = launch_ntt(st, a, p->log_n, true, path, 1);
-            return e2 == hipSuccess ? FHE_OK : hip_fail(e2, "launch_ntt");
-        });
-        if (rc) return rc;
-    }
-    for (int h = 0; h < 2; h++) {
-        u64 *tP = acc + ((size_t)h * M + L) * N;
-        // BGV: remove delta = t * [acc * t^-1]_P instead of [acc]_P, so that delta = 0 mod t
-        if (p->plain_modulus && (rc = fhe_scalar_affine(ctx, tP, tP, p->t_inv_P.data(), nullptr, t, 1, K, L, st))) return rc;
-    }
-    e = launch_baseconv_exact_jobs(st, p->down_jobs.as<BcJob>(), 2, p->down->dev.m, p->down->dev.k, p->down->dev.f64 != 0, N);
-    if (e != hipSuccess) return hip_fail(e, "launch_baseconv_exact_jobs");
-    if (p->plain_modulus && (rc = fhe_scalar_affine(ctx, conv, conv, p->t_mod_Q.data(), nullptr, t, 2, L, 0, st))) return rc;
-    if ((rc = ntt_batch(ctx, conv, t, 2, L, 0, st, false))) return rc;
-    const SubScaleArgs sa{d_out0, d_out1, acc, conv, d_add0, p->pinv.as<u64>(), (u64)(M * N), (u64)(L * N), lp, 0u, (u32)L, p->log_n, d_add1};
-    if ((e = launch_sub_scale(st, sa)) != hipSuccess) return hip_fail(e, "launch_sub_scale");
-    return FHE_OK;
+    return ks_begin(ctx, p, d_c_local, pick(ctx, stream));
 }
 
-extern "C" {
+int fhe_keyswitch_shard_inner(fhe_ctx *ctx, fhe_keyswitch *p, const uint64_t *d_c_local, const uint64_t *d_evk_local, void *stream)
+{
+    if (!ctx || !p || (!d_c_local && p->sh.cn) || !d_evk_local) return fail(FHE_ERR_INVALID, "null argument");
+    HIP_TRY(hipSetDevice(ctx->device));
+    hipStream_t st = pick(ctx, stream);
+    int rc = ks_extend_mac(ctx, p, d_c_local, d_evk_local, st);
+    return rc ? rc : ks_special_intt(ctx, p, st);
+}
+
+int fhe_keyswitch_shard_finish(fhe_ctx *ctx, fhe_keyswitch *p, uint64_t *d_out0_local, uint64_t *d_out1_local, const uint64_t *d_add0_local,
+                               const uint64_t *d_add1_local, void *stream)
+{
+    if (!ctx || !p || ((!d_out0_local || !d_out1_local) && p->sh.cn)) return fail(FHE_ERR_INVALID, "null argument");
+    HIP_TRY(hipSetDevice(ctx->device));
+    return ks_finish(ctx, p, d_out0_local, d_out1_local, d_add0_local, d_add1_local, pick(ctx, stream));
+}
 
 int fhe_rotate(fhe_ctx *ctx, fhe_keyswitch *p, uint64_t *d_out0, uint64_t *d_out1, const uint64_t *d_c0, const uint64_t *d_c1,
                uint32_t galois_elt, const uint64_t *d_galois_key, void *stream)

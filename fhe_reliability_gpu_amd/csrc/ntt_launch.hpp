@@ -123,24 +123,30 @@ struct BaseConvPlanDev {
 };
 // output limb o is written at limb index o (o < gap_at) or o + gap: lets a key-switch digit's extension land
 // in the [M][N] layout with the digit's own limbs skipped
+struct BcJob;
 hipError_t launch_baseconv_exact(hipStream_t st, u64 *out, const u64 *in, const BaseConvPlanDev &pl, u64 N, u32 gap_at = 0xFFFFFFFFu,
-                                 u32 gap = 0);
+                                 u32 gap = 0, const u32 *in_rows = nullptr);
 struct BcJob {
     BaseConvPlanDev pl;
     const u64 *in;
     u64 *out;
     u32 gap_at, gap;
+    const u32 *in_rows = nullptr;   // optional: input limb j sits at row in_rows[j] of `in` (rows of N words) instead of row j --
+                                    // the all-gathered slabs of a sharded key switch are padded per rank
 };
 hipError_t launch_baseconv_exact_jobs(hipStream_t st, const BcJob *dev_jobs, u32 n_jobs, int max_m, int max_k, bool f64, u64 N);
-// key-switch inner product over all digits and both key halves (aux_kernels.hip k_ks_mac)
+// key-switch inner product over all digits and both key halves (aux_kernels.hip k_ks_mac).  Rows are the limbs this
+// rank owns: cn ciphertext limbs (table limbs clo ..) followed by the owned special limbs (table limb = row + sp_shift);
+// one device owns everything: M = L + K, cn = L, clo = 0, sp_shift = 0.
 struct KsMacArgs {
     u64 *acc;            // [2][M][N]
-    const u64 *ext;      // [dnum][M][N]  extended digits, NTT form (own limbs unused)
-    const u64 *c;        // [L][N]        input, NTT form
+    const u64 *ext;      // [dnum][M][N]  extended digits, NTT form (the digit's own limbs unused)
+    const u64 *c;        // [cn][N]       owned input limbs, NTT form
     const u64 *evk;      // [dnum][2][M][N]
     const LimbParams *lp;
     u32 L, M, dnum, alpha;
     int logn;
+    u32 cn, clo, sp_shift;
 };
 hipError_t launch_ks_mac(hipStream_t st, const KsMacArgs &a);
 hipError_t launch_bconv_fast(hipStream_t st, u64 *out, const u64 *in, const BaseConvPlanDev &pl, u64 N);

@@ -3,8 +3,8 @@
 The reference has no multi-device code; NTT, INTT and coefficient-wise
 products are independent per limb, so ranks need no communication for them.  Only base
 conversion needs every input limb of a coefficient (motivation/baseConv.py:75-78): there the
-per-rank slabs are all-gathered (RCCL over xGMI when the backend is "nccl"; the same code
-runs on gloo/CPU tensors, which is how the tests cover it without GPUs).
+per-rank slabs are all-gathered in place into preallocated buffers (RCCL over xGMI when the backend is
+"nccl"; the same sequencing runs on gloo/CPU tensors, which is how the tests cover it without GPUs).
 
 One process per GPU, launched by torch.distributed.run; no collective inside the NTT path.
 """
@@ -28,25 +28,27 @@ def shard_table(n_limbs: int, world: int) -> List[Tuple[int, int]]:
 
 
 def gather_limbs(local, n_limbs: int, group=None):
-    """All-gather the per-rank limb slabs ``local`` (shape [hi-lo, N], any integer dtype,
-    CPU or GPU tensor) into the full [n_limbs, N] matrix on every rank."""
+    """All-gather the per-rank limb slabs ``local`` (shape [hi-lo, N], any integer dtype, CPU or GPU tensor; slab bounds
+    from limb_shard) into the full [n_limbs, N] matrix on every rank: ONE in-place all-gather of a preallocated
+    [world * rows, N] buffer (rows = the largest slab); when the slabs are equal the buffer IS the result, otherwise the
+    padding rows are squeezed out with one copy."""
     import torch
     import torch.distributed as dist
 
-    world = dist.get_world_size(group)
+    world, rank = dist.get_world_size(group), dist.get_rank(group)
     shards = shard_table(n_limbs, world)
     n = local.shape[-1]
     rows = max(hi - lo for lo, hi in shards)
-    # equal-sized buffers for all_gather; short slabs are padded with zero rows
-    pad = torch.zeros((rows, n), dtype=local.dtype, device=local.device)
-    pad[: local.shape[0]] = local
-    bufs = [torch.empty_like(pad) for _ in range(world)]
-    dist.all_gather(bufs, pad, group=group)
-    return torch.cat([bufs[r][: hi - lo] for r, (lo, hi) in enumerate(shards)], dim=0)
+    buf = torch.zeros((world * rows, n), dtype=local.dtype, device=local.device)
+    buf[rank * rows:rank * rows + local.shape[0]] = local
+    all_gather_slots(buf, rows, group)
+    if n_limbs == world * rows:
+        return buf
+    return torch.cat([buf[r * rows:r * rows + hi - lo] for r, (lo, hi) in enumerate(shards)], dim=0)
 
 
 def sharded_base_conversion(eng, local_in, mod_in: Sequence[int], mod_out: Sequence[int], group=None, exact: bool = True):
-    """Base conversion with limbs sharded over ranks (BASELINE config 4 shape).
+    """Base conversion with limbs sharded over ranks (the join of BASELINE config 4).
 
     ``local_in``: this rank's slab of the input residues, a CUDA int64 tensor [hi-lo, N]
     (slab bounds from limb_shard(len(mod_in), world, rank)).  Returns this rank's slab of
@@ -90,160 +92,172 @@ def max_over_ranks(value: float, device=None, group=None) -> float:
 # ---------------------------------------------------------------------------
 # Key switching with the RNS limbs sharded over ranks (BASELINE configs 4-5).
 #
-# Rank r owns the contiguous slab limb_shard(L + K, world, r) of the L ciphertext primes followed by the K
-# special primes: its limbs of the input, of every key digit and of the result.  NTT / INTT and the products
-# with the key are per limb, so they stay on the owner.  The two base conversions need every limb of their
-# input, hence the only two collectives:
-#   1. all-gather of the input in coefficient form  (L x N)       -> digit extension to the owner's limbs
-#   2. all-gather of the special limbs after the inner product (2 x K x N) -> mod-down to the owner's limbs
-# The per-limb work goes through a small interface (`GpuLimbOps` below: the C ABI on this rank's GPU) so the
-# same orchestration runs over gloo on CPU tensors in the tests, where the interface is backed by the oracle.
+# Rank r owns a slab of the L ciphertext primes and a slab of the K special primes (ks_layout: the C ABI's
+# fhe_keyswitch_shard_layout): its limbs of the input, of every key digit and of the result.  NTT / INTT, the digit
+# extensions to the owned limbs and the products with the key run on the owner, batched exactly as on one device
+# (include/fhe_mi355x.h, fhe_keyswitch_shard_*).  The two base conversions need every limb of their input, hence the
+# only two collectives, both in-place all-gathers of preallocated buffers (RCCL over xGMI under backend "nccl"):
+#   1. the input in coefficient form            gather1 [world][cmax][N]      (after `begin`)
+#   2. the special limbs after the inner product gather2 [world][2][smax][N]  (after `inner`)
+# `sharded_keyswitch` only sequences phases and collectives over a plan object; `ShardedKeySwitch` is the plan on this
+# rank's GPU.  tests/ run the same sequencing over gloo with a plan backed by the CPU oracle.
 # ---------------------------------------------------------------------------
-def gather_rows(local, bounds: Sequence[Tuple[int, int]], group=None):
-    """All-gather row blocks of unequal height: rank r contributes rows [bounds[r][0], bounds[r][1]) of the
-    result (its ``local`` has that many rows); every rank gets the concatenation."""
+def ks_layout(L: int, K: int, world: int, rank: int) -> dict:
+    """Owned limbs of `rank`: ciphertext limbs [clo, clo+cn), special limbs [slo, slo+sn) (table indices), and the
+    per-rank row counts of the two gather buffers (cmax, smax)."""
+    import ctypes as C
+
+    from ._lib import check, lib
+    out = (C.c_int * 6)()
+    check(lib.fhe_keyswitch_shard_layout(L, K, world, rank, out))
+    return dict(zip(("clo", "cn", "slo", "sn", "cmax", "smax"), (int(x) for x in out)))
+
+
+def _group_info(group=None):
+    import torch.distributed as dist
+    if dist.is_available() and dist.is_initialized():
+        return dist.get_world_size(group), dist.get_rank(group)
+    return 1, 0
+
+
+def all_gather_slots(buf, rows: int, group=None):
+    """In-place all-gather of ``buf`` ([world * rows, N]): every rank has filled rows [rank*rows, (rank+1)*rows).
+    One collective on a preallocated buffer, no staging copies (ncclAllGather in place under "nccl").  CUDA tensors
+    under a CPU-only backend (gloo: the 2-ranks-on-one-GPU rehearsal in tests/) are staged through host memory."""
     import torch
     import torch.distributed as dist
 
-    if not dist.is_available() or not dist.is_initialized() or dist.get_world_size(group) == 1:
-        return local
-    world = dist.get_world_size(group)
-    rows = max(1, max(hi - lo for lo, hi in bounds))
-    pad = torch.zeros((rows,) + tuple(local.shape[1:]), dtype=local.dtype, device=local.device)
-    pad[: local.shape[0]] = local
-    bufs = [torch.empty_like(pad) for _ in range(world)]
-    dist.all_gather(bufs, pad, group=group)
-    return torch.cat([bufs[r][: hi - lo] for r, (lo, hi) in enumerate(bounds)], dim=0)
+    world, rank = _group_info(group)
+    if world == 1 and not (dist.is_available() and dist.is_initialized()):
+        return
+    mine = buf[rank * rows:(rank + 1) * rows]
+    if buf.is_cuda and dist.get_backend(group) == "gloo":
+        host = torch.empty(buf.shape, dtype=buf.dtype)
+        host[rank * rows:(rank + 1) * rows] = mine.cpu()
+        dist.all_gather_into_tensor(host, host[rank * rows:(rank + 1) * rows], group=group)
+        buf.copy_(host)
+        return
+    dist.all_gather_into_tensor(buf, mine, group=group)
 
 
-class GpuLimbOps:
-    """Per-limb primitives of the sharded key switch on this rank's GPU (CUDA int64 tensors [rows, N], rows =
-    consecutive table limbs starting at ``start``), through the C ABI on torch's current stream."""
+class ShardedKeySwitch:
+    """This rank's part of a limb-sharded hybrid key switch on its GPU: the C-ABI plan (fhe_keyswitch_create_sharded)
+    plus the two gather buffers it was bound to.  All work is enqueued on torch's current stream."""
 
-    def __init__(self, eng, tables):
-        self.eng, self.t = eng, tables
-        self._plans = {}
-
-    def _call(self, fn, *args):
+    def __init__(self, eng, tables, L: int, K: int, dnum: int, group=None, force_phases: bool = True):
         import ctypes as C
 
         import torch
 
-        from ._lib import check
-        check(fn(self.eng._h, *args, C.c_void_p(torch.cuda.current_stream().cuda_stream)))
+        from ._lib import check, lib, vp
+        self.eng, self.t, self.L, self.K, self.dnum, self.group = eng, tables, L, K, dnum, group
+        self.world, self.rank = _group_info(group)
+        self.lay = ks_layout(L, K, self.world, self.rank)
+        n = tables.N
+        dev = torch.device("cuda", eng.device)
+        self.g1 = torch.zeros((self.world * self.lay["cmax"], n), dtype=torch.int64, device=dev)
+        self.g2 = torch.zeros((self.world * 2 * self.lay["smax"], n), dtype=torch.int64, device=dev)
+        h = vp()
+        check(lib.fhe_keyswitch_create_sharded(eng._h, tables._h, L, K, dnum, self.world, self.rank, C.c_void_p(self.g1.data_ptr()),
+                                               C.c_void_p(self.g2.data_ptr()), C.byref(h)))
+        self._h = h
+        self.rows1, self.rows2 = self.lay["cmax"], 2 * self.lay["smax"]
 
     @staticmethod
     def _p(x):
         import ctypes as C
-        return C.c_void_p(x.data_ptr())
+        return C.c_void_p(x.data_ptr() if x is not None and x.numel() else 0)
 
-    def intt(self, x, start):
-        from ._lib import lib
-        if x.shape[0]:
-            self._call(lib.fhe_ntt_inverse_batch, self._p(x), self.t._h, 1, x.shape[0], start)
-        return x
-
-    def ntt(self, x, start):
-        from ._lib import lib
-        if x.shape[0]:
-            self._call(lib.fhe_ntt_forward_batch, self._p(x), self.t._h, 1, x.shape[0], start)
-        return x
-
-    def baseconv(self, x, mod_in, mod_out):
-        """Exact conversion of the full input rows ``x`` ([len(mod_in), N]) to the moduli ``mod_out``."""
-        import torch
-
-        from ._lib import lib
-        from .engine import BaseConv
-        out = torch.empty((len(mod_out), x.shape[1]), dtype=torch.int64, device=x.device)
-        if mod_out:
-            key = (tuple(mod_in), tuple(mod_out))
-            if key not in self._plans:
-                self._plans[key] = BaseConv(self.eng, list(mod_in), list(mod_out))
-            self._call(lib.fhe_baseconv_exact, self._p(out), self._p(x.contiguous()), self._plans[key]._h, x.shape[1])
-        return out
-
-    def mul_acc(self, acc, a, b, start):
-        from ._lib import lib
-        if acc.shape[0]:
-            self._call(lib.fhe_modmul_acc, self._p(acc), self._p(a.contiguous()), self._p(b.contiguous()), self.t._h, 1, acc.shape[0], start)
-        return acc
-
-    def sub_scale(self, a, b, scal, start):
-        """(a - b) * scal[l] mod q_l, rows = limbs start .. start + rows."""
+    def _stream(self):
         import ctypes as C
 
         import torch
+        return C.c_void_p(torch.cuda.current_stream().cuda_stream)
 
-        from ._lib import lib
-        out = torch.empty_like(a)
-        if a.shape[0]:
-            self._call(lib.fhe_modsub, self._p(out), self._p(a.contiguous()), self._p(b.contiguous()), self.t._h, 1, a.shape[0], start)
-            mul = (C.c_uint64 * a.shape[0])(*[int(s) for s in scal])
-            self._call(lib.fhe_scalar_affine, self._p(out), self._p(out), mul, None, self.t._h, 1, a.shape[0], start)
-        return out
+    def begin(self, c_local):
+        from ._lib import check, lib
+        check(lib.fhe_keyswitch_shard_begin(self.eng._h, self._h, self._p(c_local), self._stream()))
 
-    def zeros(self, rows, n, like):
+    def inner(self, c_local, evk_local):
+        from ._lib import check, lib
+        check(lib.fhe_keyswitch_shard_inner(self.eng._h, self._h, self._p(c_local), self._p(evk_local), self._stream()))
+
+    def finish(self, add0=None, add1=None):
         import torch
-        return torch.zeros((rows, n), dtype=torch.int64, device=like.device)
+
+        from ._lib import check, lib
+        cn = self.lay["cn"]
+        out0 = torch.empty((cn, self.t.N), dtype=torch.int64, device=self.g1.device)
+        out1 = torch.empty_like(out0)
+        check(lib.fhe_keyswitch_shard_finish(self.eng._h, self._h, self._p(out0), self._p(out1), self._p(add0), self._p(add1), self._stream()))
+        return out0, out1
+
+    def close(self):
+        from ._lib import lib
+        if getattr(self, "_h", None) and self.eng._h:
+            lib.fhe_keyswitch_destroy(self._h)
+        self._h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
 
 
-def sharded_keyswitch(ops, qs: Sequence[int], L: int, K: int, dnum: int, c_local, evk_local, group=None):
-    """Hybrid RNS key switching (same arithmetic as fhe_keyswitch_apply, CKKS-style mod-down) with limbs sharded.
+def sharded_keyswitch(plan, c_local, evk_local, add0=None, add1=None, timings=None):
+    """One key switch over the ranks of ``plan.group``: begin, all-gather 1, inner, all-gather 2, finish.
 
-    qs: the L ciphertext primes followed by the K special primes.  With (mlo, mhi) = limb_shard(L + K, world, rank):
-      c_local   : rows = this rank's ciphertext limbs j in [mlo, min(mhi, L)), NTT form, [rows, N]
-      evk_local : [dnum, 2, mhi - mlo, N], this rank's limbs of every key digit, NTT form
-    Returns (out0_local, out1_local): this rank's ciphertext limbs of the result, NTT form.
-    """
+    c_local   : this rank's ciphertext limbs, NTT form, [cn, N]
+    evk_local : this rank's rows of every key digit, [dnum, 2, cn + sn, N] (ciphertext rows first), NTT form
+    add0/add1 : optional [cn, N] terms added to the two output parts (rotation: sigma(c0); relinearisation: d0, d1)
+    Returns this rank's ciphertext limbs of the two output parts.  ``timings`` (a dict) receives per-phase CUDA events
+    when given: compute phases and the two joins are then reported separately (bench.py's strong-scaling leg)."""
+    ev = None
+    if timings is not None:
+        import torch
+        ev = [torch.cuda.Event(enable_timing=True) for _ in range(6)]
+        ev[0].record()
+    plan.begin(c_local)
+    if ev:
+        ev[1].record()
+    all_gather_slots(plan.g1, plan.rows1, plan.group)
+    if ev:
+        ev[2].record()
+    plan.inner(c_local, evk_local)
+    if ev:
+        ev[3].record()
+    all_gather_slots(plan.g2, plan.rows2, plan.group)
+    if ev:
+        ev[4].record()
+    out = plan.finish(add0, add1)
+    if ev:
+        ev[5].record()
+        timings.setdefault("events", []).append(ev)
+    return out
+
+
+def sharded_rotate(plan, c0_local, c1_local, galois_elt: int, gk_local, timings=None):
+    """ROTATE with limbs sharded: the automorphism permutes slots inside each limb (no exchange), then the key switch of
+    sigma(c1) with sigma(c0) added to the first part."""
+    import ctypes as C
+
     import torch
-    import torch.distributed as dist
 
-    multi = dist.is_available() and dist.is_initialized() and dist.get_world_size(group) > 1
-    world = dist.get_world_size(group) if multi else 1
-    rank = dist.get_rank(group) if multi else 0
-    M = L + K
-    alpha = -(-L // dnum)
-    slabs = shard_table(M, world)
-    mlo, mhi = slabs[rank]
-    clo, chi = min(mlo, L), min(mhi, L)                      # owned ciphertext limbs
-    slo, shi = max(mlo, L), max(mhi, L)                      # owned special limbs
-    n = c_local.shape[-1] if c_local.shape[0] else evk_local.shape[-1]
-    c_bounds = [(min(lo, L), min(hi, L)) for lo, hi in slabs]
-    s_bounds = [(max(lo, L) - L, max(hi, L) - L) for lo, hi in slabs]
+    from ._lib import check, lib
+    s0, s1 = torch.empty_like(c0_local), torch.empty_like(c1_local)
+    st = C.c_void_p(torch.cuda.current_stream().cuda_stream)
+    if c0_local.shape[0]:
+        check(lib.fhe_automorphism_ntt(plan.eng._h, C.c_void_p(s0.data_ptr()), C.c_void_p(c0_local.data_ptr()), plan.t.log_n, galois_elt, c0_local.shape[0], st))
+        check(lib.fhe_automorphism_ntt(plan.eng._h, C.c_void_p(s1.data_ptr()), C.c_void_p(c1_local.data_ptr()), plan.t.log_n, galois_elt, c1_local.shape[0], st))
+    return sharded_keyswitch(plan, s1, gk_local, add0=s0, timings=timings)
 
-    # 1. input to coefficient form on its owner, then every rank gets all L limbs
-    coef_local = ops.intt(c_local.clone(), clo)
-    coef = gather_rows(coef_local, c_bounds, group)
 
-    # 2. per digit: extension to this rank's limbs, transform, inner product with this rank's part of the key
-    acc = [ops.zeros(mhi - mlo, n, evk_local) for _ in range(2)]
-    for d in range(dnum):
-        lo, hi = d * alpha, min(L, (d + 1) * alpha)
-        ext = ops.zeros(mhi - mlo, n, evk_local)
-        # owned limbs outside the digit come from the base extension (two runs: below and above the digit) ...
-        for a, b in ((mlo, min(mhi, lo)), (max(mlo, hi), mhi)):
-            if b > a:
-                conv = ops.baseconv(coef[lo:hi], list(qs[lo:hi]), list(qs[a:b]))
-                ext[a - mlo:b - mlo] = ops.ntt(conv, a)
-        # ... the digit's own limbs that this rank owns are the input itself
-        a, b = max(mlo, lo), min(mhi, hi)
-        if b > a:
-            ext[a - mlo:b - mlo] = c_local[a - clo:b - clo]
-        for h in range(2):
-            ops.mul_acc(acc[h], ext, evk_local[d, h], mlo)
+def own_ct_rows(lay) -> List[int]:
+    """Table indices of the ciphertext limbs a rank with layout ``lay`` owns (rows of its input / output slabs)."""
+    return list(range(lay["clo"], lay["clo"] + lay["cn"]))
 
-    # 3. mod-down: special limbs to coefficient form on their owners, all-gather, conversion to the owned ciphertext limbs
-    outs = []
-    pinv = []
-    for j in range(clo, chi):
-        pm = 1
-        for pk in qs[L:]:
-            pm = pm * (pk % qs[j]) % qs[j]
-        pinv.append(pow(pm, -1, qs[j]))
-    for h in range(2):
-        tP_local = ops.intt(acc[h][slo - mlo:shi - mlo].clone(), slo)
-        tP = gather_rows(tP_local, s_bounds, group)
-        conv = ops.ntt(ops.baseconv(tP, list(qs[L:]), list(qs[clo:chi])), clo)
-        outs.append(ops.sub_scale(acc[h][clo - mlo:chi - mlo], conv, pinv, clo))
-    return outs[0], outs[1]
+
+def own_rows(lay) -> List[int]:
+    """Table indices of every limb the rank owns, in the row order of its key slab: ciphertext limbs, then special limbs."""
+    return own_ct_rows(lay) + list(range(lay["slo"], lay["slo"] + lay["sn"]))

@@ -216,6 +216,26 @@ int fhe_automorphism_ntt(fhe_ctx *ctx, uint64_t *d_dst, const uint64_t *d_src, i
  *   d_out0, d_out1 : L x N, NTT domain; out0 + out1*s ~ c*s' when evk encrypts P*Qhat_d*[Qhat_d^-1]_{Q_d}*s'.
  * The plan owns the intermediate buffers (extended digits, accumulators): one call at a time per plan. */
 int fhe_keyswitch_create(fhe_ctx *ctx, const fhe_ntt_tables *t, int L, int K, int dnum, fhe_keyswitch **out);
+/* The same key switch with the RNS limbs sharded over `world` ranks, one process per GPU (BASELINE configs 4-5; the reference
+ * has no multi-device code).  Rank r owns the ciphertext limbs [clo, clo+cn) and the special limbs
+ * [slo, slo+sn) that fhe_keyswitch_shard_layout reports (out = {clo, cn, slo, sn, cmax, smax}; pure host function, no
+ * device needed): its rows of the input (cn x N), of every key digit (dnum x 2 x (cn+sn) x N, ciphertext rows first) and of
+ * the result.  The only exchanges are two all-gathers, issued by the host between the three phases (RCCL over xGMI when
+ * the host uses torch.distributed's "nccl" backend):
+ *   fhe_keyswitch_shard_begin   INTT of the owned input limbs into rows [rank*cmax, rank*cmax+cn) of d_gather1
+ *   -- all-gather of d_gather1 ([world][cmax][N] words, in place) --
+ *   fhe_keyswitch_shard_inner   digit extension to the owned limbs, NTT, inner product with the owned key rows, INTT of
+ *                               the owned special limbs of both halves into slot `rank` of d_gather2 ([world][2][smax][N])
+ *   -- all-gather of d_gather2 (in place) --
+ *   fhe_keyswitch_shard_finish  mod-down to the owned ciphertext limbs (+ optional addends, as a rotation / relinearisation needs)
+ * The gather buffers belong to the caller and are fixed at creation.  world = 1 gives fhe_keyswitch_create's plan. */
+int fhe_keyswitch_shard_layout(int L, int K, int world, int rank, int out[6]);
+int fhe_keyswitch_create_sharded(fhe_ctx *ctx, const fhe_ntt_tables *t, int L, int K, int dnum, int world, int rank,
+                                 uint64_t *d_gather1, uint64_t *d_gather2, fhe_keyswitch **out);
+int fhe_keyswitch_shard_begin(fhe_ctx *ctx, fhe_keyswitch *p, const uint64_t *d_c_local, void *stream);
+int fhe_keyswitch_shard_inner(fhe_ctx *ctx, fhe_keyswitch *p, const uint64_t *d_c_local, const uint64_t *d_evk_local, void *stream);
+int fhe_keyswitch_shard_finish(fhe_ctx *ctx, fhe_keyswitch *p, uint64_t *d_out0_local, uint64_t *d_out1_local,
+                               const uint64_t *d_add0_local, const uint64_t *d_add1_local, void *stream);
 /* BGV form of the mod-down: with plaintext modulus `plain_modulus` (0 = off, the CKKS-style flooring
  * above) the removed part delta satisfies delta = acc mod P and delta = 0 mod plain_modulus, so the
  * plaintext is preserved exactly (scheme of reliability_test/dotprod_test.cu:199-204). */

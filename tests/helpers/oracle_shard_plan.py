@@ -1,0 +1,97 @@
+"""A limb-sharded key-switch plan backed by the CPU oracle (TEST INFRASTRUCTURE): the same interface as
+fhe_reliability_gpu_amd.dist.ShardedKeySwitch (begin / inner / finish, gather buffers g1 / g2) on CPU int64 tensors,
+so dist.sharded_keyswitch's sequencing and the shard layout can run over gloo without a GPU.  The row maps are written
+out again here from the layout's definition (not shared with the C++ plan): the two-ranks-on-one-GPU test compares both."""
+import numpy as np
+
+
+class OracleShardPlan:
+    def __init__(self, qs, logn, L, K, dnum, group=None):
+        import torch
+
+        from fhe_reliability_gpu_amd.dist import _group_info, ks_layout
+        from oracle import cport as O
+        self.O, self.qs, self.logn, self.L, self.K, self.dnum, self.group = O, [int(q) for q in qs], logn, L, K, dnum, group
+        self.N = 1 << logn
+        self.alpha = -(-L // dnum)
+        self.world, self.rank = _group_info(group)
+        self.lays = [ks_layout(L, K, self.world, r) for r in range(self.world)]
+        self.lay = self.lays[self.rank]
+        self.cmax, self.smax = self.lay["cmax"], self.lay["smax"]
+        self.rows1, self.rows2 = self.cmax, 2 * self.smax
+        self.g1 = torch.zeros((self.world * self.cmax, self.N), dtype=torch.int64)
+        self.g2 = torch.zeros((self.world * 2 * self.smax, self.N), dtype=torch.int64)
+        self.rps = np.stack([O.root_powers(q, logn) for q in self.qs])
+        lay = self.lay
+        self.own = list(range(lay["clo"], lay["clo"] + lay["cn"])) + list(range(lay["slo"], lay["slo"] + lay["sn"]))
+
+    @staticmethod
+    def _np(x):
+        return np.ascontiguousarray(x.numpy()).view(np.uint64)
+
+    @staticmethod
+    def _t(a):
+        import torch
+        return torch.from_numpy(np.ascontiguousarray(a).view(np.int64).copy())
+
+    def _row1(self, l):
+        for r, lay in enumerate(self.lays):
+            if lay["clo"] <= l < lay["clo"] + lay["cn"]:
+                return r * self.cmax + l - lay["clo"]
+        raise AssertionError("ciphertext limb without an owner")
+
+    def _row2(self, k, h):
+        for r, lay in enumerate(self.lays):
+            if lay["slo"] <= self.L + k < lay["slo"] + lay["sn"]:
+                return (r * 2 + h) * self.smax + self.L + k - lay["slo"]
+        raise AssertionError("special limb without an owner")
+
+    def begin(self, c_local):
+        lay = self.lay
+        for j in range(lay["cn"]):
+            l = lay["clo"] + j
+            self.g1[self.rank * self.cmax + j] = self._t(self.O.nwt_inverse(self._np(c_local[j]), self.qs[l], self.rps[l]))
+
+    def inner(self, c_local, evk_local):
+        O, lay, N = self.O, self.lay, self.N
+        own = self.own
+        acc = np.zeros((2, len(own), N), dtype=np.uint64)
+        for d in range(self.dnum):
+            lo, hi = d * self.alpha, min(self.L, (d + 1) * self.alpha)
+            digit = np.stack([self._np(self.g1[self._row1(l)]) for l in range(lo, hi)])
+            for jj, tl in enumerate(own):
+                if lo <= tl < hi:
+                    x = self._np(c_local[tl - lay["clo"]])
+                else:
+                    x = O.nwt_forward(O.baseconv_exact(digit, self.qs[lo:hi], [self.qs[tl]])[0], self.qs[tl], self.rps[tl])
+                for h in range(2):
+                    acc[h, jj] = O.modmul_acc(acc[h, jj], x, self._np(evk_local[d, h, jj]), self.qs[tl])
+        self.acc = acc
+        for h in range(2):
+            for kk in range(lay["sn"]):
+                tl = lay["slo"] + kk
+                self.g2[(self.rank * 2 + h) * self.smax + kk] = self._t(O.nwt_inverse(acc[h, lay["cn"] + kk], self.qs[tl], self.rps[tl]))
+
+    def finish(self, add0=None, add1=None):
+        import torch
+        O, lay, N, L, K = self.O, self.lay, self.N, self.L, self.K
+        P = self.qs[L:L + K]
+        outs = []
+        for h, add in enumerate((add0, add1)):
+            out = torch.zeros((lay["cn"], N), dtype=torch.int64)
+            if lay["cn"]:
+                tP = np.stack([self._np(self.g2[self._row2(k, h)]) for k in range(K)])
+                for j in range(lay["cn"]):
+                    tl = lay["clo"] + j
+                    q = self.qs[tl]
+                    cn = O.nwt_forward(O.baseconv_exact(tP, P, [q])[0], q, self.rps[tl])
+                    pm = 1
+                    for pk in P:
+                        pm = pm * (pk % q) % q
+                    d = (self.acc[h, j] + (np.uint64(q) - cn)) % np.uint64(q)
+                    v = O.modmul(d, np.full(N, pow(pm, -1, q), dtype=np.uint64), q)
+                    if add is not None:
+                        v = (v + self._np(add[j]) % np.uint64(q)) % np.uint64(q)
+                    out[j] = self._t(v)
+            outs.append(out)
+        return outs[0], outs[1]

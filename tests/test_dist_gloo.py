@@ -66,107 +66,72 @@ def test_limb_shard_properties():
 
 
 # ---------------------------------------------------------------- sharded key switch (limbs over ranks, two all-gathers)
-class _OracleLimbOps:
-    """The per-limb interface of dist.sharded_keyswitch backed by the oracle on CPU int64 tensors (tests only)."""
-
-    def __init__(self, qs, logn):
-        from oracle import cport as O
-        self.O, self.qs, self.logn = O, list(qs), logn
-        self.rps = [O.root_powers(q, logn) for q in qs]
-
-    @staticmethod
-    def _np(x):
-        return np.ascontiguousarray(x.numpy()).view(np.uint64)
-
-    @staticmethod
-    def _t(a):
-        import torch
-        return torch.from_numpy(np.ascontiguousarray(a).view(np.int64).copy())
-
-    def intt(self, x, start):
-        for r in range(x.shape[0]):
-            x[r] = self._t(self.O.nwt_inverse(self._np(x[r]), self.qs[start + r], self.rps[start + r]))
-        return x
-
-    def ntt(self, x, start):
-        for r in range(x.shape[0]):
-            x[r] = self._t(self.O.nwt_forward(self._np(x[r]), self.qs[start + r], self.rps[start + r]))
-        return x
-
-    def baseconv(self, x, mod_in, mod_out):
-        import torch
-        if not mod_out:
-            return torch.zeros((0, x.shape[1]), dtype=torch.int64)
-        return self._t(self.O.baseconv_exact(self._np(x), list(mod_in), list(mod_out)))
-
-    def mul_acc(self, acc, a, b, start):
-        for r in range(acc.shape[0]):
-            acc[r] = self._t(self.O.modmul_acc(self._np(acc[r]), self._np(a[r]), self._np(b[r]), self.qs[start + r]))
-        return acc
-
-    def sub_scale(self, a, b, scal, start):
-        import torch
-        out = torch.zeros_like(a)
-        for r in range(a.shape[0]):
-            q = self.qs[start + r]
-            d = (self._np(a[r]).astype(object) - self._np(b[r]).astype(object)) % q
-            out[r] = self._t(((d * int(scal[r])) % q).astype(np.uint64))
-        return out
-
-    def zeros(self, rows, n, like):
-        import torch
-        return torch.zeros((rows, n), dtype=torch.int64)
-
-
 def _ks_case(logn, L, K, dnum):
     from oracle import cport as O
     N = 1 << logn
     qs = [int(q) for q in O.gen_primes(N, 30, L + K)]
     rng = np.random.default_rng(L * 100 + K * 10 + dnum)
     c = np.stack([rng.integers(0, q, N, dtype=np.uint64) for q in qs[:L]])
+    add = np.stack([rng.integers(0, q, N, dtype=np.uint64) for q in qs[:L]])
     evk = np.stack([np.stack([np.stack([rng.integers(0, q, N, dtype=np.uint64) for q in qs]) for _ in range(2)]) for _ in range(dnum)])
-    return qs, c, evk
+    return qs, c, evk, add
 
 
 def _ks_worker(rank, world, port, logn, L, K, dnum, out_dir):
     import torch
     import torch.distributed as dist
 
-    from fhe_reliability_gpu_amd.dist import limb_shard, sharded_keyswitch
+    from fhe_reliability_gpu_amd.dist import ks_layout, own_ct_rows, own_rows, sharded_keyswitch
+    from helpers.oracle_shard_plan import OracleShardPlan
 
     os.environ["MASTER_ADDR"] = "127.0.0.1"
     os.environ["MASTER_PORT"] = str(port)
     dist.init_process_group("gloo", rank=rank, world_size=world)
     try:
-        qs, c, evk = _ks_case(logn, L, K, dnum)
-        mlo, mhi = limb_shard(L + K, world, rank)
+        qs, c, evk, add = _ks_case(logn, L, K, dnum)
+        lay = ks_layout(L, K, world, rank)
         to_t = lambda a: torch.from_numpy(np.ascontiguousarray(a).view(np.int64).copy())
-        c_local = to_t(c[min(mlo, L):min(mhi, L)])
-        evk_local = to_t(evk[:, :, mlo:mhi])
-        o0, o1 = sharded_keyswitch(_OracleLimbOps(qs, logn), qs, L, K, dnum, c_local, evk_local)
+        plan = OracleShardPlan(qs, logn, L, K, dnum)
+        o0, o1 = sharded_keyswitch(plan, to_t(c[own_ct_rows(lay)]), to_t(evk[:, :, own_rows(lay)]), add0=to_t(add[own_ct_rows(lay)]))
         np.save(os.path.join(out_dir, f"ks{rank}.npy"), np.stack([o0.numpy().view(np.uint64), o1.numpy().view(np.uint64)]))
     finally:
         dist.destroy_process_group()
 
 
-@pytest.mark.parametrize("world,L,K,dnum", [(2, 4, 2, 2), (3, 5, 2, 3), (2, 3, 1, 3)])
+@pytest.mark.parametrize("world,L,K,dnum", [(2, 4, 2, 2), (3, 5, 2, 3), (2, 3, 1, 3), (3, 2, 4, 1)])
 def test_sharded_keyswitch_gloo(tmp_path, world, L, K, dnum):
-    """Limbs sharded over ranks, all-gathers at the two base-conversion joins: the concatenated per-rank results equal the
-    single-device key switch (oracle/keyswitch_ref.py, the composite the GPU tests pin fhe_keyswitch_apply to)."""
+    """Limbs sharded over ranks, in-place all-gathers at the two base-conversion joins: the concatenated per-rank results equal
+    the single-device key switch (oracle/keyswitch_ref.py, the composite the GPU tests pin fhe_keyswitch_apply to).  Covers
+    uneven slabs, a rank without special limbs and (L = 2, world = 3) a rank without ciphertext limbs."""
     import torch.multiprocessing as mp
-    from fhe_reliability_gpu_amd.dist import limb_shard
+    from fhe_reliability_gpu_amd.dist import ks_layout
     from oracle.keyswitch_ref import keyswitch_ref
 
     logn = 6
     port = _free_port()
     mp.spawn(_ks_worker, args=(world, port, logn, L, K, dnum, str(tmp_path)), nprocs=world, join=True)
-    qs, c, evk = _ks_case(logn, L, K, dnum)
-    want0, want1 = keyswitch_ref(c, evk, qs, L, K, dnum, logn)
+    qs, c, evk, add = _ks_case(logn, L, K, dnum)
+    want0, want1 = keyswitch_ref(c, evk, qs, L, K, dnum, logn, add0=add)
     got = [np.load(tmp_path / f"ks{r}.npy") for r in range(world)]
     got0 = np.concatenate([g[0] for g in got], axis=0)
     got1 = np.concatenate([g[1] for g in got], axis=0)
     assert got0.shape == want0.shape and (got0 == want0).all() and (got1 == want1).all()
-    # a rank that owns only special primes returns no ciphertext limbs
     for r in range(world):
-        lo, hi = limb_shard(L + K, world, r)
-        assert got[r].shape[1] == max(0, min(hi, L) - min(lo, L))
+        assert got[r].shape[1] == ks_layout(L, K, world, r)["cn"]
+
+
+def test_ks_layout_tiles_both_limb_sets():
+    """Every ciphertext limb and every special limb has exactly one owner; slab sizes differ by at most one; the total
+    per rank (the work per rank) differs by at most one more; cmax / smax are the largest slabs."""
+    from fhe_reliability_gpu_amd.dist import ks_layout, own_ct_rows, own_rows
+    for L, K in ((44, 11), (44, 4), (44, 1), (32, 8), (4, 2), (2, 4), (16, 4)):
+        for world in (1, 2, 3, 4, 8):
+            lays = [ks_layout(L, K, world, r) for r in range(world)]
+            ct = sorted(sum((own_ct_rows(l) for l in lays), []))
+            allr = sorted(sum((own_rows(l) for l in lays), []))
+            assert ct == list(range(L)) and allr == list(range(L + K))
+            assert max(l["cn"] for l in lays) - min(l["cn"] for l in lays) <= 1
+            assert max(l["sn"] for l in lays) - min(l["sn"] for l in lays) <= 1
+            assert all(l["cmax"] == max(x["cn"] for x in lays) and l["smax"] == max(x["sn"] for x in lays) for l in lays)
+            tot = [l["cn"] + l["sn"] for l in lays]
+            assert max(tot) - min(tot) <= 1, (L, K, world, tot)

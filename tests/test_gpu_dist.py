@@ -1,0 +1,153 @@
+"""The limb-sharded key switch on the GPU: the C-ABI phase path against fhe_keyswitch_apply and the
+oracle, an executed RCCL join (backend "nccl", one rank -- a one-GPU box cannot host more RCCL ranks), and the real
+multi-rank plan with two and three ranks sharing the one GPU, exchanged over gloo."""
+import os
+import socket
+
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+def _case(logn, L, K, dnum, bits=50, seed=0):
+    import fhe_reliability_gpu_amd as F
+    N = 1 << logn
+    qs = F.create_moduli(N, [bits] * L + [61 if bits == 61 else 50] * K)
+    rng = np.random.default_rng(seed + 1000 * L + 10 * K + dnum)
+    c = np.stack([rng.integers(0, q, N, dtype=np.uint64) for q in qs[:L]])
+    add = np.stack([rng.integers(0, q, N, dtype=np.uint64) for q in qs[:L]])
+    evk = np.stack([np.stack([np.stack([rng.integers(0, q, N, dtype=np.uint64) for q in qs]) for _ in range(2)]) for _ in range(dnum)])
+    return qs, c, evk, add
+
+
+def _to_cuda(a):
+    import torch
+    return torch.from_numpy(np.ascontiguousarray(a).view(np.int64).copy()).cuda()
+
+
+def _from_cuda(t):
+    return t.cpu().numpy().view(np.uint64)
+
+
+@pytest.mark.parametrize("logn,L,K,dnum,bits", [(13, 5, 2, 3, 50), (12, 6, 3, 2, 61), (10, 22, 11, 2, 50)])
+def test_phase_path_on_one_rank_equals_apply(logn, L, K, dnum, bits):
+    """fhe_keyswitch_create_sharded with world = 1 (gather buffers bound, slots = whole buffers) run phase by phase equals
+    fhe_keyswitch_apply word for word, with and without an addend."""
+    import torch
+
+    import fhe_reliability_gpu_amd as F
+    from fhe_reliability_gpu_amd.dist import ShardedKeySwitch, sharded_keyswitch
+    eng = F.default_engine()
+    qs, c, evk, add = _case(logn, L, K, dnum, bits)
+    t = eng.tables(logn, qs)
+    w0, w1 = F.KeySwitch(eng, t, L, K, dnum).apply(eng.upload(c), eng.upload(evk))
+    w0, w1 = w0.download(), w1.download()
+    plan = ShardedKeySwitch(eng, t, L, K, dnum)
+    with torch.cuda.stream(torch.cuda.Stream()):
+        o0, o1 = sharded_keyswitch(plan, _to_cuda(c), _to_cuda(evk))
+        a0, a1 = sharded_keyswitch(plan, _to_cuda(c), _to_cuda(evk), add0=_to_cuda(add), add1=_to_cuda(add))
+        torch.cuda.current_stream().synchronize()
+    assert (_from_cuda(o0) == w0).all() and (_from_cuda(o1) == w1).all()
+    qcol = np.array(qs[:L], dtype=np.uint64)[:, None]
+    assert (_from_cuda(a0) == (w0 + add) % qcol).all() and (_from_cuda(a1) == (w1 + add) % qcol).all()
+
+
+def _nccl_worker(rank, world, port, out_dir):
+    # fresh process: nothing has touched the GPU before the process group exists
+    import torch
+    import torch.distributed as dist
+
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    torch.cuda.set_device(0)
+    dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", 0))
+    try:
+        import fhe_reliability_gpu_amd as F
+        from fhe_reliability_gpu_amd.dist import ShardedKeySwitch, limb_shard, sharded_base_conversion, sharded_keyswitch, sharded_rotate
+        from oracle import cport as O
+        from oracle.keyswitch_ref import rotate_ref
+        eng = F.Engine(0)
+        logn, L, K, dnum = 13, 6, 2, 3
+        qs, c, evk, add = _case(logn, L, K, dnum)
+        t = eng.tables(logn, qs)
+        w0, w1 = F.KeySwitch(eng, t, L, K, dnum).apply(eng.upload(c), eng.upload(evk))
+        plan = ShardedKeySwitch(eng, t, L, K, dnum)
+        tm = {}
+        o0, o1 = sharded_keyswitch(plan, _to_cuda(c), _to_cuda(evk), timings=tm)
+        r0, r1 = sharded_rotate(plan, _to_cuda(add), _to_cuda(c), 5, _to_cuda(evk))
+        torch.cuda.synchronize()
+        ok_ks = bool((_from_cuda(o0) == w0.download()).all() and (_from_cuda(o1) == w1.download()).all())
+        v0, v1 = rotate_ref(add, c, 5, evk, qs, L, K, dnum, logn)
+        ok_rot = bool((_from_cuda(r0) == v0).all() and (_from_cuda(r1) == v1).all())
+        ev = tm["events"][0]
+        gather_ms = ev[1].elapsed_time(ev[2]) + ev[3].elapsed_time(ev[4])
+        # the base-conversion join of config 4 through the same backend
+        lo, hi = limb_shard(L, world, rank)
+        out = sharded_base_conversion(eng, _to_cuda(c[lo:hi]), qs[:L], qs[L:])
+        olo, ohi = limb_shard(K, world, rank)
+        ok_bc = bool((_from_cuda(out) == O.baseconv_exact(c, qs[:L], qs[L:])[olo:ohi]).all())
+        np.save(os.path.join(out_dir, f"nccl{rank}.npy"), np.array([ok_ks, ok_rot, ok_bc, gather_ms >= 0.0, dist.get_backend() == "nccl"]))
+    finally:
+        dist.destroy_process_group()
+
+
+def test_rccl_join_executes_on_one_rank(tmp_path):
+    """A real RCCL process group (backend "nccl"): sharded_keyswitch, sharded_rotate and sharded_base_conversion issue their
+    all-gathers through ncclAllGather and reproduce the single-device results.  One rank: RCCL refuses two ranks on one GPU,
+    and this box has one; the driver's 8-GPU run is where world > 1 meets RCCL."""
+    import torch.multiprocessing as mp
+    mp.spawn(_nccl_worker, args=(1, _free_port(), str(tmp_path)), nprocs=1, join=True)
+    flags = np.load(tmp_path / "nccl0.npy")
+    assert flags.all(), f"(keyswitch, rotate, baseconv, timings, backend) = {flags.tolist()}"
+
+
+def _gloo_gpu_worker(rank, world, port, logn, L, K, dnum, bits, out_dir):
+    import torch
+    import torch.distributed as dist
+
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        import fhe_reliability_gpu_amd as F
+        from fhe_reliability_gpu_amd.dist import ShardedKeySwitch, ks_layout, own_ct_rows, own_rows, sharded_keyswitch
+        eng = F.Engine(0)
+        qs, c, evk, add = _case(logn, L, K, dnum, bits)
+        t = eng.tables(logn, qs)
+        lay = ks_layout(L, K, world, rank)
+        plan = ShardedKeySwitch(eng, t, L, K, dnum)
+        assert plan.lay == lay
+        o0, o1 = sharded_keyswitch(plan, _to_cuda(c[own_ct_rows(lay)]), _to_cuda(evk[:, :, own_rows(lay)]), add0=_to_cuda(add[own_ct_rows(lay)]))
+        torch.cuda.synchronize()
+        np.save(os.path.join(out_dir, f"g{rank}.npy"), np.stack([_from_cuda(o0), _from_cuda(o1)]))
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("world,logn,L,K,dnum,bits", [(2, 12, 5, 3, 2, 50), (3, 11, 7, 2, 3, 50), (2, 13, 4, 1, 4, 61), (3, 10, 2, 4, 1, 50)])
+def test_real_plan_with_ranks_sharing_the_gpu(tmp_path, world, logn, L, K, dnum, bits):
+    """The C-ABI sharded plan with world = 2 / 3 (every rank computes on cuda:0, the joins go over gloo through host memory):
+    gather-buffer row maps, per-digit gaps, a rank without special limbs, a rank without ciphertext limbs -- the concatenated
+    results equal the oracle composite.  This is the multi-rank device code the 8-GPU RCCL run executes."""
+    import torch.multiprocessing as mp
+    from fhe_reliability_gpu_amd.dist import ks_layout
+    from oracle.keyswitch_ref import keyswitch_ref
+    mp.spawn(_gloo_gpu_worker, args=(world, _free_port(), logn, L, K, dnum, bits, str(tmp_path)), nprocs=world, join=True)
+    qs, c, evk, add = _case(logn, L, K, dnum, bits)
+    w0, w1 = keyswitch_ref(c, evk, qs, L, K, dnum, logn, add0=add)
+    got = [np.load(tmp_path / f"g{r}.npy") for r in range(world)]
+    g0 = np.concatenate([g[0] for g in got], axis=0)
+    g1 = np.concatenate([g[1] for g in got], axis=0)
+    assert g0.shape == w0.shape and (g0 == w0).all() and (g1 == w1).all()
+    for r in range(world):
+        assert got[r].shape[1] == ks_layout(L, K, world, r)["cn"]

@@ -231,26 +231,3 @@ def test_rotate_is_stream_capture_safe(F, eng):
     graph.replay()
     torch.cuda.synchronize()
     assert bool((o0 == want0).all()) and bool((o1 == want1).all())
-
-
-def test_sharded_keyswitch_gpu_ops_match_fused_plan(F, eng):
-    """dist.sharded_keyswitch through the C ABI (GpuLimbOps) on one rank = fhe_keyswitch_apply, word for word; the
-    multi-rank orchestration of the same function is covered over gloo in tests/test_dist_gloo.py."""
-    import torch
-    from fhe_reliability_gpu_amd.dist import GpuLimbOps, sharded_keyswitch
-    logn, L, K, dnum = 13, 5, 2, 3
-    n = 1 << logn
-    qs = F.create_moduli(n, [50, 50, 61, 50, 50, 50, 61])
-    t = eng.tables(logn, qs)
-    ks = F.KeySwitch(eng, t, L, K, dnum)
-    rng = np.random.default_rng(42)
-    c = np.stack([rng.integers(0, q, n, dtype=np.uint64) for q in qs[:L]])
-    evk = np.stack([np.stack([np.stack([rng.integers(0, q, n, dtype=np.uint64) for q in qs]) for _ in range(2)]) for _ in range(dnum)])
-    w0, w1 = ks.apply(eng.upload(c), eng.upload(evk))
-    w0, w1 = w0.download(), w1.download()
-    to_t = lambda a: torch.from_numpy(np.ascontiguousarray(a).view(np.int64).copy()).cuda()
-    with torch.cuda.stream(torch.cuda.Stream()):
-        o0, o1 = sharded_keyswitch(GpuLimbOps(eng, t), qs, L, K, dnum, to_t(c), to_t(evk))
-        torch.cuda.current_stream().synchronize()
-    assert (o0.cpu().numpy().view(np.uint64) == w0).all()
-    assert (o1.cpu().numpy().view(np.uint64) == w1).all()
