@@ -9,13 +9,22 @@ A "step" is one forward NTT pass (nwt_2d_radix8_forward_inplace semantics,
 reliability_test/ntt_test.cu:95) over one batch of residue polynomials that is already
 resident in HBM.  Default workload = BASELINE.json configs[1]: N = 2^16, a single
 50-bit prime (the reference's prime size, ntt_test.cu:44), batched over --polys
-polynomials so that the 256 CUs are filled.  --limbs L switches to L distinct primes
-per polynomial (configs[2] shape).  Multi-GPU: residue polynomials are independent, so
-every rank transforms its own batch (weak scaling, no collective on the data path).
+polynomials.  The default batch is 1024 polynomials = 512 MiB: larger than the 256 MiB
+Infinity Cache, so every sweep of a step is HBM traffic and `roofline.frac` is a
+fraction of the HBM roofline in the literal sense (the 128 MiB batch that stays in the
+Infinity Cache is reported beside it as `frac_cache_resident`).  --limbs L switches to L
+distinct primes per polynomial (configs[2] shape).
+
+Multi-GPU: residue polynomials are independent, so every rank transforms its own batch
+(weak scaling, no collective on the data path, `value` = all ranks' NTTs / max time).  The
+path's one exchange -- the base-conversion join of key switching -- is measured by the
+strong-scaling leg `also.strong_scaling_config5` (BASELINE configs[4]: N = 2^16, L = 44
+limbs sharded over the ranks, two RCCL all-gathers per rotation, compute and joins timed
+separately).
 
 Prints ONE JSON line on rank 0 (contract in the task statement) with `roofline`
 (algorithmic bytes 16*N per limb-NTT / HIP-event time vs 8 TB/s) and `cpu_baseline`
-(the oracle's C port timed on one host core).
+(the oracle's C port on one core and on all host cores, and the pure-Python form).
 """
 import argparse
 import json
@@ -31,18 +40,28 @@ N = 1 << LOGN
 HBM_PEAK_GBS = 8000.0  # MI355X_MICROARCH.md: HBM3E 8 TB/s spec
 
 
+def _py_ntt_task(args):
+    """One pure-Python forward NTT of a limb (worker of the all-cores CPU leg; imports only the oracle's Python port)."""
+    a, q, rp, reps = args
+    from oracle import pyport as PY
+    t = time.perf_counter()
+    for _ in range(reps):
+        PY.nwt_forward(a, q, rp)
+    return time.perf_counter() - t
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=1000)
-    ap.add_argument("--warmup", type=int, default=200)
-    ap.add_argument("--polys", type=int, default=256, help="residue polynomials per limb in the batch")
+    ap.add_argument("--steps", type=int, default=300)
+    ap.add_argument("--warmup", type=int, default=60)
+    ap.add_argument("--polys", type=int, default=1024, help="residue polynomials per limb in the batch (1024 = 512 MiB: HBM streaming)")
     ap.add_argument("--limbs", type=int, default=1, help="distinct RNS primes per polynomial")
     ap.add_argument("--bits", type=int, default=50, help="prime size (50 = reference; 61 = integer path)")
     ap.add_argument("--no-cpu", action="store_true", help="skip the CPU baseline leg")
     ap.add_argument("--check", action="store_true", help="verify one limb against the oracle before timing")
     ap.add_argument("--mode", choices=["fused", "twopass"], default="twopass")
-    ap.add_argument("--no-extras", action="store_true", help="skip the secondary measurements (other batch shapes)")
+    ap.add_argument("--no-extras", action="store_true", help="skip the secondary measurements (other batch shapes, composites)")
     ap.add_argument("--streams", type=int, default=2,
                     help="HIP streams the batch's polynomials are sharded over inside one GPU (each step = one call per stream)")
     args = ap.parse_args()
@@ -55,6 +74,7 @@ def main():
     if world > 1:
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
         dist.init_process_group(backend="nccl", device_id=torch.device("cuda", local_rank))
     torch.cuda.set_device(local_rank)
 
@@ -77,22 +97,22 @@ def main():
     data = torch.empty((args.polys, args.limbs, N), dtype=torch.int64, device="cuda")
     for l, q in enumerate(qs):
         data[:, l, :] = torch.randint(0, q, (args.polys, N), generator=g, device="cuda", dtype=torch.int64)
-    pristine = data.clone()
+    first_limb = data[0, 0].clone()
     torch.cuda.synchronize()
     # a non-default torch stream: its handle is non-null, so the library launches on it and
     # torch.cuda.Event timestamps see the kernels
     stream = torch.cuda.Stream()
     sptr = C.c_void_p(stream.cuda_stream)
     assert stream.cuda_stream != 0
-    dptr = C.c_void_p(data.data_ptr())
+    P = lambda x: C.c_void_p(x.data_ptr())
 
     def step():
-        check(lib.fhe_ntt_forward_batch(eng._h, dptr, tables._h, args.polys, args.limbs, 0, sptr))
+        check(lib.fhe_ntt_forward_batch(eng._h, P(data), tables._h, args.polys, args.limbs, 0, sptr))
 
     # The headline loop shards the batch's polynomials over `--streams` HIP streams (north_star: "RNS limbs shard
     # one-per-stream and then one-per-GPU"): polynomials are independent, every stream transforms its own slab in
     # place, one library call per stream per step, no synchronisation between steps -- so one slab's column pass
-    # runs under another slab's row pass and the kernel tails overlap (measured: -8 % against one stream).
+    # runs under another slab's row pass and the kernel tails overlap.
     n_str = max(1, min(args.streams, args.polys))
     streams = [stream] + [torch.cuda.Stream() for _ in range(n_str - 1)]
     bounds = [(i * args.polys // n_str, (i + 1) * args.polys // n_str) for i in range(n_str)]
@@ -105,13 +125,13 @@ def main():
 
     if args.check and rank == 0:
         from oracle import cport as O
+        keep = data[0, 0].clone()
         step()
         torch.cuda.synchronize()
         eng.check()
         got = data[0, 0].cpu().numpy().view(np.uint64)
-        want = O.nwt_forward(pristine[0, 0].cpu().numpy().view(np.uint64), qs[0], O.root_powers(qs[0], LOGN))
+        want = O.nwt_forward(keep.cpu().numpy().view(np.uint64), qs[0], O.root_powers(qs[0], LOGN))
         assert (got == want).all(), "GPU forward NTT differs from the oracle"
-        data.copy_(pristine)
 
     def barrier():
         if world > 1:
@@ -144,6 +164,8 @@ def main():
     alg_bytes_per_step = 16.0 * N * units                # 16*N bytes per limb-NTT
     step_ms_dev = dev_ms / args.steps
     achieved = alg_bytes_per_step / (step_ms_dev * 1e-3) / 1e9
+    batch_mib = args.polys * args.limbs * N * 8 >> 20
+    streaming = batch_mib > 256
 
     result = {
         "metric": "forward negacyclic NTT/s at N=2^16 (limb-polynomials per second)",
@@ -160,7 +182,8 @@ def main():
         "data": "synthetic",
         "config": {
             "workload": f"N=2^16 forward NTT, {args.limbs} x {args.bits}-bit prime(s), batch of {args.polys} residue polynomials per GPU "
-                        f"({args.polys * args.limbs * N * 8 >> 20} MiB), in place, resident on the device before the timed region",
+                        f"({batch_mib} MiB, {'exceeds' if streaming else 'fits'} the 256 MiB Infinity Cache), in place, resident on the device "
+                        f"before the timed region",
             "log_n": LOGN, "limbs": args.limbs, "polys_per_gpu": args.polys, "prime_bits": args.bits,
             "parallelism": f"limb-polynomials sharded over {world} GPU(s), no collective; {n_str} stream(s) per GPU",
             "streams_per_gpu": n_str,
@@ -168,41 +191,50 @@ def main():
         "roofline": {
             "bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
             "traffic": None,
+            "regime": "hbm_streaming" if streaming else "infinity_cache_resident",
             "kernel": ("k_ntt_fused (one launch per step)" if args.mode == "fused" else "column pass + row pass (two launches per slab per step)")
                       + "; achieved = 16*N*units bytes / HIP-event time of the step (first launch to the last stream's end, / steps)",
             "ms_per_step_device": step_ms_dev,
         },
     }
+    if streaming:
+        result["roofline"]["frac_hbm_streaming"] = achieved / HBM_PEAK_GBS
+    else:
+        result["roofline"]["frac_cache_resident"] = achieved / HBM_PEAK_GBS
 
-    # each kernel of the step timed on its own, inside real transforms (the two launches issued as two calls with an event
-    # between them): the column pass and the row pass each move the batch once in and once out, i.e. 16*N bytes per
-    # limb-polynomial per LAUNCH; the transform needs both
-    if args.mode == "twopass":
-        marks = []
-        n_pairs = min(args.steps, 100)
-        for i in range(n_pairs + 5):
-            ev = [torch.cuda.Event(enable_timing=True) for _ in range(3)]
-            eng.set_option("ntt_only_pass", 0)
-            ev[0].record(stream)
-            step()
-            ev[1].record(stream)
-            eng.set_option("ntt_only_pass", 1)
-            step()
-            ev[2].record(stream)
-            if i >= 5:
-                marks.append(ev)
-        eng.set_option("ntt_only_pass", -1)
+    def timed_loop(fn, steps, warm, on=stream):
+        for _ in range(warm):
+            fn()
         torch.cuda.synchronize()
+        a0, a1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        a0.record(on)
+        for _ in range(steps):
+            fn()
+        a1.record(on)
+        torch.cuda.synchronize()
+        return a0.elapsed_time(a1) / steps
+
+    # each kernel of the step timed on its own, inside real transforms on ONE stream: a block of column-pass launches and a
+    # block of row-pass launches over the same batch (each moves the batch once in and once out: 16*N bytes per
+    # limb-polynomial per LAUNCH; the transform needs both).  Always >= 200 launches per block, whatever --steps is; the
+    # rocprofv3 kernel trace of this command (profiles/) must agree with these averages.
+    if args.mode == "twopass" and rank == 0:
         per_launch = {}
         for k, name in ((0, "column_pass"), (1, "row_pass")):
-            ms = sum(e[k].elapsed_time(e[k + 1]) for e in marks) / len(marks)
-            per_launch[name] = {"avg_launch_ms": ms, "GBps_moved": alg_bytes_per_step / (ms * 1e-3) / 1e9,
+            eng.set_option("ntt_only_pass", k)
+            ms = timed_loop(step, 200, 20)
+            per_launch[name] = {"avg_launch_ms": ms, "launches_timed": 200, "GBps_moved": alg_bytes_per_step / (ms * 1e-3) / 1e9,
                                 "frac_of_peak": alg_bytes_per_step / (ms * 1e-3) / 1e9 / HBM_PEAK_GBS}
+        eng.set_option("ntt_only_pass", -1)
         result["roofline"]["per_launch"] = per_launch
+        one_stream_ms = timed_loop(step, 200, 20)
+        result["roofline"]["ms_per_step_one_stream"] = one_stream_ms
+    else:
+        one_stream_ms = None
 
-    # HBM/fabric bytes per step from the PMC passes committed under profiles/ (same command,
-    # FETCH_SIZE doubled as MI355X_MICROARCH.md prescribes and as calibrated on this access
-    # pattern, plus WRITE_SIZE); only quoted for the configuration it was collected on
+    # HBM/fabric bytes per launch pair from the PMC passes committed under profiles/ (rocprofv3 --pmc on this very command
+    # line, FETCH_SIZE doubled as MI355X_MICROARCH.md prescribes and as calibrated on this access pattern, plus WRITE_SIZE):
+    # a per-launch property of the kernels on this batch shape, quoted only for the configuration it was collected on
     tpath = os.path.join(ROOT, "profiles", "traffic.json")
     if os.path.exists(tpath):
         with open(tpath) as fh:
@@ -212,8 +244,11 @@ def main():
             result["roofline"]["traffic"] = tr[key]["bytes_per_step"]
             result["roofline"]["traffic_note"] = tr[key]["note"]
 
-    # secondary measurements on rank 0 (not the headline): same kernels, other batch shapes
-    if rank == 0 and not args.no_extras and world == 1:
+    extras = not args.no_extras
+    also = {}
+
+    # ------------------------------------------------------------------ secondary measurements (rank 0, one GPU)
+    if rank == 0 and extras and world == 1:
         def rate(limbs, polys, bits, inverse=False, steps=300):
             q2 = F.create_moduli(N, [bits] * limbs)
             t2 = eng.tables(LOGN, q2)
@@ -222,20 +257,43 @@ def main():
                 buf[:, l, :] = torch.randint(0, q, (polys, N), generator=g, device="cuda", dtype=torch.int64)
             torch.cuda.synchronize()
             fn = lib.fhe_ntt_inverse_batch if inverse else lib.fhe_ntt_forward_batch
-            call = lambda: check(fn(eng._h, C.c_void_p(buf.data_ptr()), t2._h, polys, limbs, 0, sptr))
-            for _ in range(max(3, steps // 4)):
-                call()
-            torch.cuda.synchronize()
-            a0, a1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-            a0.record(stream)
-            for _ in range(steps):
-                call()
-            a1.record(stream)
-            torch.cuda.synchronize()
-            ms = a0.elapsed_time(a1) / steps
+            ms = timed_loop(lambda: check(fn(eng._h, P(buf), t2._h, polys, limbs, 0, sptr)), steps, max(3, steps // 4))
             del buf
             return {"ntt_per_s": limbs * polys / (ms * 1e-3), "ms_per_step_device": ms,
                     "frac_of_hbm_roofline": 16.0 * N * limbs * polys / (ms * 1e-3) / 1e9 / HBM_PEAK_GBS}
+
+        # the batch that stays inside the Infinity Cache (round 1's headline shape), same two-stream loop
+        small = 256
+        sm_args = [(C.c_void_p(data.data_ptr() + (i * small // n_str) * args.limbs * N * 8), (i + 1) * small // n_str - i * small // n_str,
+                    C.c_void_p(st.cuda_stream)) for i, st in enumerate(streams)]
+
+        def step_small():
+            for ptr, cnt, sp in sm_args:
+                check(lib.fhe_ntt_forward_batch(eng._h, ptr, tables._h, cnt, args.limbs, 0, sp))
+        if args.polys >= small:
+            for _ in range(200):
+                step_small()
+            torch.cuda.synchronize()
+            e0 = torch.cuda.Event(enable_timing=True)
+            ee = [torch.cuda.Event(enable_timing=True) for _ in streams]
+            e0.record(stream)
+            for _ in range(1000):
+                step_small()
+            for e, st in zip(ee, streams):
+                e.record(st)
+            torch.cuda.synchronize()
+            ms = max(e0.elapsed_time(e) for e in ee) / 1000
+            fr = 16.0 * N * small * args.limbs / (ms * 1e-3) / 1e9 / HBM_PEAK_GBS
+            result["roofline"]["frac_cache_resident"] = fr
+            also["cache_resident_256_polys_128MiB (fits the 256 MiB Infinity Cache; round 1's headline shape)"] = {
+                "ntt_per_s": small * args.limbs / (ms * 1e-3), "ms_per_step_device": ms, "frac_of_hbm_roofline": fr,
+                "note": "the batch is re-read from the Infinity Cache, not from HBM: a fabric-rate figure, not an HBM-rate one"}
+
+        also["inverse_same_batch"] = rate(args.limbs, args.polys, args.bits, inverse=True, steps=100)
+        also["L16_distinct_primes_x16_polys (configs[2] shape, 128 MiB)"] = rate(16, 16, args.bits)
+        also["L16_distinct_primes_x64_polys (512 MiB, HBM streaming)"] = rate(16, 64, args.bits, steps=100)
+        also["61bit_prime_integer_path_same_batch"] = rate(1, args.polys, 61, steps=100)
+
         def pointwise_rates():
             # coefficient-wise products and base conversion at the configs[2] shape (N = 2^16, L = 16)
             L2, P2 = 16, 16
@@ -243,20 +301,8 @@ def main():
             t2 = eng.tables(LOGN, q2)
             mk = lambda: torch.randint(0, q2[0], (P2, L2, N), generator=g, device="cuda", dtype=torch.int64)
             a, b, c = mk(), mk(), mk()
-            pa, pb, pc = (C.c_void_p(x.data_ptr()) for x in (a, b, c))
-            def timed(fn, steps=200):
-                for _ in range(50):
-                    fn()
-                torch.cuda.synchronize()
-                a0, a1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-                a0.record(stream)
-                for _ in range(steps):
-                    fn()
-                a1.record(stream)
-                torch.cuda.synchronize()
-                return a0.elapsed_time(a1) / steps
             units2 = L2 * P2
-            ms_mul = timed(lambda: check(lib.fhe_modmul(eng._h, pc, pa, pb, t2._h, P2, L2, 0, sptr)))
+            ms_mul = timed_loop(lambda: check(lib.fhe_modmul(eng._h, P(c), P(a), P(b), t2._h, P2, L2, 0, sptr)), 200, 50)
             # fhe_polymul uses its factors as scratch: restore them (untimed) before every timed call
             a_keep, b_keep = a.clone(), b.clone()
             pairs = []
@@ -266,7 +312,7 @@ def main():
                     b.copy_(b_keep)
                     e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
                     e0.record(stream)
-                    check(lib.fhe_polymul(eng._h, pc, pa, pb, t2._h, P2, L2, 0, sptr))
+                    check(lib.fhe_polymul(eng._h, P(c), P(a), P(b), t2._h, P2, L2, 0, sptr))
                     e1.record(stream)
                     if i >= 3:
                         pairs.append((e0, e1))
@@ -283,85 +329,110 @@ def main():
             bc = F.BaseConv(eng, q2[:m_in], q2[m_in:m_in + k_out])
             src = torch.randint(0, q2[0], (m_in, 64 * N), generator=g, device="cuda", dtype=torch.int64)
             dst = torch.empty((k_out, 64 * N), dtype=torch.int64, device="cuda")
-            ms_bc = timed(lambda: check(lib.fhe_baseconv_exact(eng._h, C.c_void_p(dst.data_ptr()), C.c_void_p(src.data_ptr()), bc._h, 64 * N, sptr)))
+            ms_bc = timed_loop(lambda: check(lib.fhe_baseconv_exact(eng._h, P(dst), P(src), bc._h, 64 * N, sptr)), 200, 50)
             out["baseconv_exact_4to4_N=2^22"] = {"ms_per_step_device": ms_bc,
                                                  "frac_of_hbm_roofline": 8.0 * 64 * N * (m_in + k_out) / (ms_bc * 1e-3) / 1e9 / HBM_PEAK_GBS}
             return out
-        result["also"] = {
-            "inverse_same_batch": rate(args.limbs, args.polys, args.bits, inverse=True),
-            "L16_distinct_primes_x16_polys (configs[2] shape)": rate(16, 16, args.bits),
-            "hbm_streaming_1024_polys_512MiB (exceeds the 256 MiB Infinity Cache)": rate(1, 1024, args.bits, steps=60),
-            "61bit_prime_integer_path": rate(1, args.polys, 61),
-        }
-        result["also"].update(pointwise_rates())
+        also.update(pointwise_rates())
 
-        def keyswitch_rates():
-            # hybrid key switching: random NTT-form input and key, timing only
+        def composite_rates():
+            # the composites BASELINE configs[3] and [4] time, on one GPU (parity: tests/test_gpu_configs45.py), plus the two
+            # round-1 shapes.  Random NTT-form inputs and keys; algorithmic bytes = every operand the caller hands over or gets
+            # back, once: input parts + key + output parts (8 bytes per word).
             out = {}
-            for name, logn, L, K, dnum, reps in (("keyswitch_N=2^16_L16_K4_dnum4", 16, 16, 4, 4, 10),
-                                                 ("rotate_N=2^14_L4_K1_dnum4 (shape of the reference's SEAL trace, 2543 us on its CPU)", 14, 4, 1, 4, 50)):
+            shapes = (
+                ("keyswitch_N=2^16_L16_K4_dnum4", "keyswitch", 16, 16, 4, 4, 20),
+                ("rotate_N=2^14_L4_K1_dnum4 (shape of the reference's SEAL trace, 2543 us on its CPU)", "rotate", 14, 4, 1, 4, 100),
+                ("config5_rotate_N=2^16_L44_K11_dnum4 (BASELINE configs[4] on one GPU)", "rotate", 16, 44, 11, 4, 10),
+                ("config5_rotate_N=2^16_L44_K4_dnum11 (BASELINE configs[4], dnum sweep of draw_dnum_rot_mul.py:63-65)", "rotate", 16, 44, 4, 11, 10),
+                ("config4_hmult_N=2^17_L32_K8_dnum4 (BASELINE configs[3] on one GPU: multiply + relinearize + rescale)", "hmult", 17, 32, 8, 4, 10),
+            )
+            for name, kind, logn, L, K, dnum, reps in shapes:
                 n = 1 << logn
                 qk = F.create_moduli(n, [args.bits] * (L + K))
                 tk = eng.tables(logn, qk)
                 ks = F.KeySwitch(eng, tk, L, K, dnum)
-                c0 = torch.randint(0, qk[0], (L, n), generator=g, device="cuda", dtype=torch.int64)
-                c1 = torch.randint(0, qk[0], (L, n), generator=g, device="cuda", dtype=torch.int64)
-                evk = torch.randint(0, qk[0], (dnum, 2, L + K, n), generator=g, device="cuda", dtype=torch.int64)
-                o0, o1 = torch.empty_like(c0), torch.empty_like(c0)
-                P = lambda x: C.c_void_p(x.data_ptr())
-                if name.startswith("rotate"):
+                mk = lambda *shape: torch.randint(0, qk[0], shape, generator=g, device="cuda", dtype=torch.int64)
+                c0, c1, b0, b1 = mk(L, n), mk(L, n), mk(L, n), mk(L, n)
+                evk = mk(dnum, 2, L + K, n)
+                lo = L - 1 if kind == "hmult" else L
+                o0, o1 = torch.empty((lo, n), dtype=torch.int64, device="cuda"), torch.empty((lo, n), dtype=torch.int64, device="cuda")
+                key_words = dnum * 2 * (L + K)
+                if kind == "rotate":
                     call = lambda: check(lib.fhe_rotate(eng._h, ks._h, P(o0), P(o1), P(c0), P(c1), 3, P(evk), sptr))
+                    words = 2 * L + key_words + 2 * L
+                elif kind == "hmult":
+                    call = lambda: check(lib.fhe_hmult(eng._h, ks._h, P(o0), P(o1), P(c0), P(c1), P(b0), P(b1), P(evk), 1, sptr))
+                    words = 4 * L + key_words + 2 * (L - 1)
                 else:
                     call = lambda: check(lib.fhe_keyswitch_apply(eng._h, ks._h, P(o0), P(o1), P(c0), P(evk), sptr))
+                    words = L + key_words + 2 * L
                 for _ in range(3):
                     call()
                 torch.cuda.synchronize()
                 e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-                t0 = time.perf_counter()
+                tw = time.perf_counter()
                 e0.record(stream)
                 for _ in range(reps):
                     call()
                 e1.record(stream)
                 torch.cuda.synchronize()
-                wall = (time.perf_counter() - t0) / reps
+                wall_c = (time.perf_counter() - tw) / reps
                 dev = e0.elapsed_time(e1) / reps
-                # bytes every key switch must move at least once: input, key, two outputs
-                alg = 8.0 * n * (L + dnum * 2 * (L + K) + 2 * L)
-                out[name] = {"us_per_call_device": dev * 1e3, "us_per_call_wall": wall * 1e6,
-                             "frac_of_hbm_roofline (input + key + outputs once)": alg / (dev * 1e-3) / 1e9 / HBM_PEAK_GBS}
-                del ks
+                alg = 8.0 * n * words
+                # limb-NTT count of the composite: INTT of the input, the extended limbs of every digit, the special limbs
+                # of both halves and the converted limbs of the mod-down (+ the rescale's for hmult)
+                ntt_count = L + dnum * (L + K) - L + 2 * K + 2 * L + (2 + 2 * (L - 1) if kind == "hmult" else 0)
+                out[name] = {"us_per_call_device": dev * 1e3, "us_per_call_wall": wall_c * 1e6, "limb_ntts_per_call": ntt_count,
+                             "limb_ntt_per_s_inside": ntt_count / (dev * 1e-3),
+                             "algorithmic_bytes": alg, "frac_of_hbm_roofline (inputs + key + outputs once)": alg / (dev * 1e-3) / 1e9 / HBM_PEAK_GBS}
+                del ks, evk
             return out
-        result["also"].update(keyswitch_rates())
+        also.update(composite_rates())
+
+        def fourstep_rate():
+            # four_step_ntt (reliability_test/four_step_ntt_prot.py:71-109) at 2^16 = 256 x 256 and 2^17 = 512 x 256, MOD = 998244353
+            out = {}
+            for n1, n2 in ((256, 256), (512, 256)):
+                nn = n1 * n2
+                if (998244353 - 1) % nn:
+                    continue
+                h = C.c_void_p()
+                check(lib.fhe_fourstep_create(eng._h, n1, n2, 998244353, 3, C.byref(h)))
+                src = torch.randint(0, 998244353, (nn,), generator=g, device="cuda", dtype=torch.int64)
+                dst = torch.empty_like(src)
+                ms = timed_loop(lambda: check(lib.fhe_fourstep_ntt(eng._h, P(dst), P(src), h, sptr)), 200, 20)
+                out[f"fourstep_{n1}x{n2}_single_vector"] = {"us_per_call_device": ms * 1e3,
+                                                            "frac_of_hbm_roofline (16N bytes)": 16.0 * nn / (ms * 1e-3) / 1e9 / HBM_PEAK_GBS}
+                lib.fhe_fourstep_destroy(h)
+            return out
+        also.update(fourstep_rate())
 
         def abft_rate():
-            # forward transform with the weighted-checksum detector on the headline batch
+            # forward transform with the weighted-checksum detector on the headline batch, against the
+            # unchecked transform on the SAME single stream and batch
             ab = F.Abft(eng, tables)
             flags = torch.zeros(args.polys * args.limbs, dtype=torch.int32, device="cuda")
-            call = lambda: check(lib.fhe_ntt_forward_checked(eng._h, C.c_void_p(data.data_ptr()), tables._h, ab._h, args.polys, args.limbs, 0,
-                                                             C.c_void_p(flags.data_ptr()), sptr))
-            for _ in range(3):
-                call()
-            torch.cuda.synchronize()
-            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-            e0.record(stream)
-            for _ in range(20):
-                call()
-            e1.record(stream)
-            torch.cuda.synchronize()
-            ms = e0.elapsed_time(e1) / 20
-            return {"abft_checked_forward_same_batch": {"ms_per_step_device": ms, "overhead_vs_unchecked": ms / step_ms_dev - 1.0,
+            call = lambda: check(lib.fhe_ntt_forward_checked(eng._h, P(data), tables._h, ab._h, args.polys, args.limbs, 0, P(flags), sptr))
+            ms = timed_loop(call, 50, 5)
+            base = one_stream_ms if one_stream_ms else timed_loop(step, 50, 5)
+            return {"abft_checked_forward_same_batch": {"ms_per_step_device": ms, "unchecked_ms_same_stream": base,
+                                                        "overhead_vs_unchecked_same_stream": ms / base - 1.0,
                                                         "flags_raised": int(flags.sum().item())}}
-        result["also"].update(abft_rate())
+        also.update(abft_rate())
 
         def pcie_inclusive():
             # the boundary can hand over HOST buffers (ntt_test does): pinned host -> device, transform, device -> host
-            host = torch.empty((args.polys, args.limbs, N), dtype=torch.int64).pin_memory()
-            host.copy_(pristine.cpu())
+            cnt = min(args.polys, 256)
+            host = torch.empty((cnt, args.limbs, N), dtype=torch.int64).pin_memory()
+            host.copy_(data[:cnt].cpu())
+            dev = data[:cnt]
+
             def call():
                 with torch.cuda.stream(stream):
-                    data.copy_(host, non_blocking=True)
-                    step()
-                    host.copy_(data, non_blocking=True)
+                    dev.copy_(host, non_blocking=True)
+                    check(lib.fhe_ntt_forward_batch(eng._h, P(dev), tables._h, cnt, args.limbs, 0, sptr))
+                    host.copy_(dev, non_blocking=True)
             call()
             torch.cuda.synchronize()
             t = time.perf_counter()
@@ -369,34 +440,134 @@ def main():
                 call()
             torch.cuda.synchronize()
             dt = (time.perf_counter() - t) / 5
-            return {"pcie_inclusive_same_batch (pinned host in, host out; not the headline)": {
-                "ms_per_step_wall": dt * 1e3, "ntt_per_s": units / dt, "GBps_each_way": args.polys * args.limbs * N * 8 / (dt / 2) / 1e9}}
-        result["also"].update(pcie_inclusive())
+            return {"pcie_inclusive_256_polys (pinned host in, host out; not the headline)": {
+                "ms_per_step_wall": dt * 1e3, "ntt_per_s": cnt * args.limbs / dt, "GBps_each_way": cnt * args.limbs * N * 8 / (dt / 2) / 1e9}}
+        also.update(pcie_inclusive())
 
-    if rank == 0 and world == 1 and not args.no_cpu:      # the CPU leg runs at N = 1 only
+    # ------------------------------------------------------------------ strong scaling: config 5 with the limbs sharded
+    if extras:
+        def strong_scaling():
+            # BASELINE configs[4]: one rotation at N = 2^16, L = 44, K = 11, dnum = 4 with the limbs sharded over the ranks
+            # (fhe_keyswitch_shard_* phases on each GPU, two in-place RCCL all-gathers: dist.sharded_rotate).  Total work is
+            # fixed as the rank count grows; per call: the three compute phases and the two joins from CUDA events on this
+            # rank's stream, max over ranks.
+            from fhe_reliability_gpu_amd.dist import ShardedKeySwitch, ks_layout, sharded_rotate
+            logn, L, K, dnum, reps = 16, 44, 11, 4, 20
+            n = 1 << logn
+            qk = F.create_moduli(n, [args.bits] * (L + K))
+            tk = eng.tables(logn, qk)
+            lay = ks_layout(L, K, world, rank)
+            mo = lay["cn"] + lay["sn"]
+            gg = torch.Generator(device="cuda")
+            gg.manual_seed(7 + rank)
+            mk = lambda *shape: torch.randint(0, qk[0], shape, generator=gg, device="cuda", dtype=torch.int64)
+            c0, c1, gk = mk(lay["cn"], n), mk(lay["cn"], n), mk(dnum, 2, mo, n)
+            plan = ShardedKeySwitch(eng, tk, L, K, dnum)
+            with torch.cuda.stream(stream):
+                for _ in range(3):
+                    sharded_rotate(plan, c0, c1, 3, gk)
+                barrier()
+                tm = {}
+                tw = time.perf_counter()
+                for _ in range(reps):
+                    sharded_rotate(plan, c0, c1, 3, gk, timings=tm)
+                barrier()
+                wall_c = (time.perf_counter() - tw) / reps
+            evs = tm["events"]
+            seg = [sum(e[i].elapsed_time(e[i + 1]) for e in evs) / len(evs) for i in range(5)]
+            vals = torch.tensor([seg[0] + seg[2] + seg[4], seg[1], seg[3], sum(seg), wall_c * 1e3], device="cuda", dtype=torch.float64)
+            if world > 1:
+                dist.all_reduce(vals, op=dist.ReduceOp.MAX)
+            comp, j1, j2, tot, wl = (float(x) for x in vals.tolist())
+            ntt_count = L + dnum * (L + K) - L + 2 * K + 2 * L
+            return {"strong_scaling_config5": {
+                "workload": f"one rotation, N=2^16, L={L}, K={K}, dnum={dnum}, limbs sharded over {world} rank(s) "
+                            f"(rank 0 owns {lay['cn']} ciphertext + {lay['sn']} special limbs)",
+                "scaling": "strong", "n_gpus": world, "backend": (dist.get_backend() if world > 1 else "none (1 rank: no collective issued)"),
+                "us_per_rotation_device": tot * 1e3, "us_per_rotation_wall": wl * 1e3,
+                "us_compute_phases": comp * 1e3, "us_all_gather_1 (input, coefficient form)": j1 * 1e3,
+                "us_all_gather_2 (special limbs of both halves)": j2 * 1e3,
+                "bytes_all_gather_1_per_rank": plan.rows1 * n * 8, "bytes_all_gather_2_per_rank": plan.rows2 * n * 8,
+                "limb_ntts_per_rotation": ntt_count, "limb_ntt_per_s": ntt_count / (tot * 1e-3)}}
+        try:
+            ss = strong_scaling()
+            if rank == 0:
+                also.update(ss)
+        except Exception as ex:       # the headline must survive a failure of this leg; it is reported, not hidden
+            if rank == 0:
+                also["strong_scaling_config5"] = {"error": repr(ex)}
+    if rank == 0 and also:
+        result["also"] = also
+
+    # ------------------------------------------------------------------ CPU baselines (rank 0, one GPU)
+    if rank == 0 and world == 1 and not args.no_cpu:
         from oracle import cport as O
+        from oracle import pyport as PY
+        cores = os.cpu_count() or 1
         rp = O.root_powers(qs[0], LOGN)
-        a = pristine[0, 0].cpu().numpy().view(np.uint64)
-        O.nwt_forward(a, qs[0], rp)                      # warm
+        a = first_limb.cpu().numpy().view(np.uint64)
+        # (1) the C port on ONE core: the scalar restatement (u128 mulmod), ~5 s
+        O.set_threads(1)
+        O.nwt_forward(a, qs[0], rp)
         reps, t = 0, time.perf_counter()
-        while time.perf_counter() - t < 10.0:
+        while time.perf_counter() - t < 5.0:
             O.nwt_forward(a, qs[0], rp)
             reps += 1
-        cpu_s = (time.perf_counter() - t) / reps
-        # the reference's own CPU path is pure Python (motivation/ntt.py, rfhe_framewk/src/negaclic_ntt.py):
-        # the oracle's Python restatement of it on the same limb, a few repetitions
-        from oracle import pyport as PY
+        c1 = reps / (time.perf_counter() - t)
+        # (2) the C port on ALL host cores: independent limbs spread by OpenMP (cpu_cxx_allcores), ~5 s
+        used = O.set_threads(cores)
+        lim = max(16, 2 * used)
+        batch = np.stack([a] * lim)
+        qv, rpv = [qs[0]] * lim, np.stack([rp] * lim)
+        O.nwt_forward_batch(batch, qv, rpv)
+        rb, t = 0, time.perf_counter()
+        while time.perf_counter() - t < 5.0:
+            O.nwt_forward_batch(batch, qv, rpv)
+            rb += 1
+        call_c = rb * lim / (time.perf_counter() - t)
+        # (3) the reference's own CPU form is pure Python (motivation/ntt.py, rfhe_framewk/src/negaclic_ntt.py): the
+        # oracle's Python restatement on the same limb, one core, a few repetitions
         a_list, rp_list = [int(x) for x in a], [int(x) for x in rp]
         py_reps, t = 0, time.perf_counter()
-        while py_reps < 2 or (time.perf_counter() - t < 6.0 and py_reps < 16):
+        while py_reps < 2 or (time.perf_counter() - t < 5.0 and py_reps < 16):
             PY.nwt_forward(a_list, qs[0], rp_list)
             py_reps += 1
-        py_s = (time.perf_counter() - t) / py_reps
+        py1 = py_reps / (time.perf_counter() - t)
+        # (4) the same on all cores: multiprocessing.Pool, one independent limb per task (BASELINE.md cpu_python_allcores)
+        py_all = None
+        try:
+            import multiprocessing as mp
+            ctx = mp.get_context("spawn")       # workers never touch the GPU; spawn keeps them clear of this process's HIP state
+            with ctx.Pool(cores) as pool:
+                pool.map(_py_ntt_task, [(a_list[:256], qs[0], rp_list[:256], 1)] * cores)      # start the workers (untimed)
+                t = time.perf_counter()
+                pool.map(_py_ntt_task, [(a_list, qs[0], rp_list, 1)] * (2 * cores))
+                py_all = 2 * cores / (time.perf_counter() - t)
+        except Exception as ex:
+            py_all = repr(ex)
+        # (5) BASELINE configs[0]: N = 2^12, one 61-bit prime, cyclic NTT with motivation/ntt.py semantics (generator root)
+        q61, root = 2305843009211596801, 37
+        import random
+        rnd = random.Random(12)
+        v12 = [rnd.randrange(q61) for _ in range(1 << 12)]
+        PY.ntt_cyclic(v12, q61, root)
+        r12, t = 0, time.perf_counter()
+        while time.perf_counter() - t < 2.0:
+            PY.ntt_cyclic(v12, q61, root)
+            r12 += 1
+        c0_py = r12 / (time.perf_counter() - t)
         result["cpu_baseline"] = {
-            "value": 1.0 / cpu_s, "unit": "NTT/s", "cores": 1, "kind": "port",
-            "sample": f"{reps} forward NTTs of one N=2^16 limb (oracle/fhe_oracle.c orc_nwt_forward, u128 mulmod, gcc -O3), ~10 s",
-            "pure_python": {"value": 1.0 / py_s, "unit": "NTT/s", "cores": 1,
-                            "sample": f"{py_reps} forward NTTs of the same limb with oracle/pyport.py nwt_forward (Python integers, the reference's CPU form)"},
+            "value": call_c, "unit": "NTT/s", "cores": used, "kind": "port",
+            "sample": f"{rb} batches of {lim} forward NTTs of an N=2^16 limb, limbs spread over {used} host threads by OpenMP "
+                      f"(oracle/fhe_oracle.c orc_nwt_forward_batch, u128 mulmod, gcc -O3), ~5 s",
+            "one_core": {"value": c1, "unit": "NTT/s", "cores": 1, "sample": f"{reps} forward NTTs of one N=2^16 limb (orc_nwt_forward), ~5 s"},
+            "pure_python_one_core": {"value": py1, "unit": "NTT/s", "cores": 1,
+                                     "sample": f"{py_reps} forward NTTs of the same limb with oracle/pyport.py nwt_forward (Python integers, the reference's CPU form)"},
+            "pure_python_all_cores": {"value": py_all, "unit": "NTT/s", "cores": cores,
+                                      "sample": f"{2 * cores} independent limbs over multiprocessing.Pool({cores}), same function"},
+            "config0_N=2^12_61bit_cyclic_python": {"value": c0_py, "unit": "NTT/s", "cores": 1,
+                                                   "sample": f"{r12} cyclic NTTs (oracle/pyport.py ntt_cyclic = motivation/ntt.py:8-32 semantics), q61={q61}, root={root}"},
+            "host_cores": cores,
         }
     if rank == 0:
         print(json.dumps(result))

@@ -274,11 +274,11 @@ template <int MAXM, class B, bool STAGE_>
 __device__ __forceinline__ void bc_exact_body(const BcJob &job, u64 N, u32 oc)
 {
     typedef typename B::acc_t T;
-    constexpr int UNR = MAXM <= 8 ? MAXM : 1;   // small bases: digits in registers; larger ones index a scratch array
+    constexpr int UNR = MAXM <= 16 ? MAXM : 1;   // bases up to 16 limbs (key-switch digits): digits in registers, loops unrolled; larger ones index a scratch array
     // Short launches of small bases (N = 2^16: a single wave of workgroups) stage their constants in LDS once per
     // workgroup: read through scalar loads inside the loops they were bound by those loads' round trips.  Long
     // launches keep the scalar loads (operands in SGPRs cost nothing once other waves hide the latency).
-    constexpr bool STAGE = STAGE_ && MAXM <= 8;
+    constexpr bool STAGE = STAGE_ && MAXM <= 16;
     constexpr int OCMAX = 64;
     __shared__ Tw s_dig[STAGE ? MAXM * MAXM : 1], s_hor[STAGE ? MAXM * OCMAX : 1], s_fpi[STAGE ? MAXM : 1], s_fpo[STAGE ? OCMAX : 1];
     __shared__ u64 s_pi[STAGE ? MAXM : 1], s_qo[STAGE ? OCMAX : 1];
@@ -365,7 +365,7 @@ static void launch_exact(hipStream_t st, dim3 grid, const BcJob *dev_jobs, const
 {
 #define FHE_BC(MM)                                                                                                    \
     do {                                                                                                              \
-        const bool stage = MM <= 8 && (u64)grid.x * grid.y * grid.z <= 8192;                                           \
+        const bool stage = MM <= 16 && (u64)grid.x * grid.y * grid.z <= 8192;                                          \
         if (dev_jobs && stage) hipLaunchKernelGGL((k_baseconv_exact_jobs<MM, B, true>), grid, dim3(256), 0, st, dev_jobs, N, oc);  \
         else if (dev_jobs) hipLaunchKernelGGL((k_baseconv_exact_jobs<MM, B, false>), grid, dim3(256), 0, st, dev_jobs, N, oc);     \
         else if (stage) hipLaunchKernelGGL((k_baseconv_exact<MM, B, true>), grid, dim3(256), 0, st, job, N, oc);        \
@@ -373,6 +373,7 @@ static void launch_exact(hipStream_t st, dim3 grid, const BcJob *dev_jobs, const
     } while (0)
     if (maxm <= 4) FHE_BC(4);
     else if (maxm <= 8) FHE_BC(8);
+    else if (maxm <= 12) FHE_BC(12);
     else if (maxm <= 16) FHE_BC(16);
     else if (maxm <= 32) FHE_BC(32);
     else FHE_BC(64);

@@ -159,6 +159,7 @@ int fhe_ctx_create(int device, fhe_ctx **out)
     if (const char *v = getenv("FHE_FUSED_WGS")) c->fused_wgs = (unsigned)std::max(1, atoi(v));
     if (const char *v = getenv("FHE_NTT_RESIDENT")) c->resident = atoi(v) != 0;
     if (const char *v = getenv("FHE_NTT_PACKED")) c->packed_on = atoi(v) != 0;
+    if (const char *v = getenv("FHE_KS_FUSED")) c->ks_fused = atoi(v) < 0 ? -1 : atoi(v) ? 1 : 0;
     *out = c.release();
     return FHE_OK;
 }
@@ -187,6 +188,7 @@ int fhe_ctx_set_option(fhe_ctx *ctx, const char *name, long value)
     else if (!std::strcmp(name, "tile_geo")) ctx->geo = value ? 1 : 0;
     else if (!std::strcmp(name, "ntt_resident")) ctx->resident = value != 0;
     else if (!std::strcmp(name, "ntt_packed")) ctx->packed_on = value != 0;
+    else if (!std::strcmp(name, "ks_fused")) ctx->ks_fused = value < 0 ? -1 : value ? 1 : 0;
     else if (!std::strcmp(name, "ntt_only_pass")) ctx->only_pass = value == 0 ? 0 : value == 1 ? 1 : -1;   // bench.py times each kernel with it
     else if (!std::strcmp(name, "fused_skip_teams")) ctx->fused_skip_teams = (unsigned)value;   // test hook
     else return fail(FHE_ERR_INVALID, "unknown option");

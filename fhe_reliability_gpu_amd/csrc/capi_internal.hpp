@@ -106,6 +106,7 @@ struct fhe_ctx {
     int fault_bit = 0;
     int geo = 1;           // column-tile geometry of the two-launch path (ntt_launch.hpp)
     bool resident = false; // 2^13 / 2^14: one LDS-resident pass instead of two launches (opt-in, see ntt_plan.hpp)
+    int ks_fused = -1;     // key-switch inner product fused with the extended limbs' row pass: -1 = by shape, 0 = never, 1 = always (where supported)
     int only_pass = -1;    // measurement hook: 0 / 1 = launch only the first / second pass of a two-pass size
     int fused_variant = 7;   // handoff*2 + stream hint (ntt_launch.hpp); 7 = acquire + nt streaming
     // cyclic tables keyed by (log_n, mod, root, convention)
@@ -140,6 +141,7 @@ struct fhe_keyswitch {
     u64 *g1 = nullptr, *g2 = nullptr;   // gather buffers: [world][cmax][N] coefficient-form input, [world][2][smax][N] special limbs
     DevBuf up_rows, down_rows;          // row of each conversion input limb inside g1 / g2 (or acc on one device)
     bool up_f64 = false;
+    bool own_path[2] = {false, false};  // arithmetic paths present among the owned limbs
     u32 n_up_jobs = 0;
     std::vector<BcJob> up_host;         // host copy of the digit jobs (mixed arithmetic paths: one launch per digit)
     u64 plain_modulus = 0;              // BGV: delta must vanish modulo this (0 = CKKS-style flooring)

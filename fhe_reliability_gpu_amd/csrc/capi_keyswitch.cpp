@@ -67,6 +67,7 @@ static int ks_create(fhe_ctx *ctx, const fhe_ntt_tables *t, int L, int K, int dn
     const KsShard &sh = p->sh;
     const size_t N = (size_t)1 << t->log_n, MO = (size_t)sh.cn + sh.sn;   // owned limbs: rows of ext / acc / the key
     p->m_own = (int)MO;
+    for (size_t jj = 0; jj < MO; jj++) p->own_path[t->path[jj < (size_t)sh.cn ? (size_t)sh.clo + jj : (size_t)sh.slo + (jj - sh.cn)]] = true;
     auto limb_of = [&](size_t jj) { return jj < (size_t)sh.cn ? (size_t)sh.clo + jj : (size_t)sh.slo + (jj - sh.cn); };
     HIP_TRY(hipSetDevice(ctx->device));
     // per digit: where the digit's limbs sit in gather buffer 1, which owned rows it skips, and the conversion to the rest
@@ -206,6 +207,11 @@ static int ks_extend_mac(fhe_ctx *ctx, fhe_keyswitch *p, const uint64_t *d_c, co
     u64 *ext = p->ext.as<u64>(), *acc = p->acc.as<u64>();
     hipError_t e;
     if (!MO) return FHE_OK;
+    // with the fused inner product only the FIRST launch of the extended limbs' forward transform runs on its own (the column
+    // pass; nothing at all for single-pass sizes): the row pass happens inside the MULTEVK launch, tile by tile
+    // (by shape: the fused launch has m_own x tiles workgroups, each looping over the digits -- it pays once that fills the chip)
+    const bool want = ctx->ks_fused < 0 ? (MO << (p->log_n > 12 ? p->log_n - 12 : 0)) >= 640 : ctx->ks_fused != 0;
+    const bool fused = want && ks_rowmac_supported(p->log_n) && ctx->fault_idx < 0;
     {
         // (one trace line for the phase; the nested NTT line precedes it, as the reference's tools expect of nested costs)
         TraceScope tr_mr(ctx, st, "MODREDUCTION");
@@ -220,15 +226,16 @@ static int ks_extend_mac(fhe_ctx *ctx, fhe_keyswitch *p, const uint64_t *d_c, co
         }
         TraceScope tr_ntt(ctx, st, "NTT");
         for (int path = 0; path < 2; path++) {
-            if (!p->ext_units[path]) continue;
+            if (!p->ext_units[path] || (fused && p->log_n <= 12)) continue;
             PassArgs a{ext, lp, 0u, 1u, p->ext_units[path], 1u, p->ext_map[path].as<UnitRef>()};
-            if ((e = launch_ntt(st, a, p->log_n, false, path, 1)) != hipSuccess) return hip_fail(e, "launch_ntt");
+            if ((e = launch_ntt(st, a, p->log_n, false, path, 1, fused ? 0 : -1)) != hipSuccess) return hip_fail(e, "launch_ntt");
         }
     }
     // multiply-accumulate with the evaluation key (MULTEVK): all digits, both halves, one launch
     TraceScope tr_mk(ctx, st, "MULTEVK");
     const KsMacArgs ka{acc, ext, d_c, d_evk, lp, (u32)p->L, (u32)MO, (u32)p->dnum, (u32)p->alpha, p->log_n, (u32)sh.cn, (u32)sh.clo, (u32)(sh.slo - sh.cn)};
-    if ((e = launch_ks_mac(st, ka)) != hipSuccess) return hip_fail(e, "launch_ks_mac");
+    e = fused ? launch_ks_rowmac(st, ka, p->own_path[0], p->own_path[1]) : launch_ks_mac(st, ka);
+    if (e != hipSuccess) return hip_fail(e, "launch_ks_mac");
     return FHE_OK;
 }
 

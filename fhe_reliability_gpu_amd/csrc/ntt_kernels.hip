@@ -512,6 +512,140 @@ hipError_t launch_polymul(hipStream_t st, const PassArgs &a, u64 *b, u64 *c, int
     return hipSuccess;
 }
 
+// ---------------------------------------------------------------------------
+// Key-switch inner product fused with the last pass of the forward transform of the extended digits (MULTEVK with the NTT
+// that precedes it in the reference's trace, profile_framewk/build/data/ckks/16384_4:471-452).  One workgroup = one owned
+// limb (row jj of ext / acc / the key) x one row tile.  For every digit d: the limb's row-pass steps run on ext[d][jj]'s
+// tile in LDS (the digit's own limbs take the NTT-form input c instead), each thread then picks up its 16-byte pairs of the
+// finished tile where the copy-out phase would, multiplies by the two key halves and adds into registers.  After the last
+// digit the two sums are written once.  Exact integer arithmetic in both paths: the result equals k_ks_mac's word for word.
+// ---------------------------------------------------------------------------
+template <class A, int LOGN, int GEO>
+__global__ __launch_bounds__(NTT_THREADS, 2) void k_ks_rowmac(KsMacArgs a)
+{
+    typedef typename MidPasses<A, LOGN, GEO>::Fwd FR;
+    static_assert(FR::STAGED, "fused inner product needs the staged row pass");
+    typedef typename FR::elem elem;
+    constexpr int PAIRS = FR::TROWS * FR::NPTS / 2;
+    constexpr int PER = (PAIRS + NTT_THREADS - 1) / NTT_THREADS;
+    __shared__ __attribute__((aligned(16))) elem lds[FR::LDS_ELEMS];
+    const u32 jj = blockIdx.x / FR::TILES, tile = blockIdx.x % FR::TILES;
+    const u32 tl = jj < a.cn ? a.clo + jj : jj + a.sp_shift;         // table limb of this row
+    const LimbParams &p = a.lp[tl];
+    if (p.path != A::PATH) return;                                   // the other instantiation's limb (uniform per workgroup)
+    const typename A::Ctx ctx = A::make_ctx(p);
+    const Tw inv_n = p.inv_n;
+    const TwPtr tw = as_global(p.fwd);
+    const int tid = threadIdx.x;
+    const u32 row0 = tile * FR::TROWS;
+    const size_t toff = (size_t)row0 * FR::NPTS;                      // tile offset inside a limb
+    elem s0[PER][2], s1[PER][2];
+#pragma unroll
+    for (int k = 0; k < PER; k++) s0[k][0] = s0[k][1] = s1[k][0] = s1[k][1] = elem(0);
+    int terms = 0;
+    for (u32 d = 0; d < a.dnum; d++) {
+        const u32 lo = d * a.alpha, hi = lo + a.alpha < a.L ? lo + a.alpha : a.L;
+        const bool own = jj < a.cn && tl >= lo && tl < hi;
+        if (!own) {
+            u64 *src = const_cast<u64 *>(a.ext) + (((size_t)d * a.M + jj) << LOGN) + toff;
+            if (d) __syncthreads();                                  // the previous digit's pairs have been read
+            fwd_steps<FR>(tid, src, lds, tw, row0, ctx, inv_n);
+            __syncthreads();
+        }
+        const u64 *k0 = a.evk + ((((size_t)d * 2) * a.M + jj) << LOGN) + toff, *k1 = k0 + ((size_t)a.M << LOGN);
+        ++terms;
+#pragma unroll
+        for (int k = 0; k < PER; k++) {
+            const int i = tid + k * NTT_THREADS;
+            if (PAIRS % NTT_THREADS == 0 || i < PAIRS) {
+                const u32 row = (u32)i / (FR::NPTS / 2), g = ((u32)i % (FR::NPTS / 2)) * 2;
+                const size_t off = (size_t)row * FR::NPTS + g;
+                ulonglong2 cw = ulonglong2{0, 0};
+                if (own) cw = *reinterpret_cast<const ulonglong2 *>(a.c + ((size_t)jj << LOGN) + toff + off);
+                ulonglong2 w0 = *reinterpret_cast<const ulonglong2 *>(k0 + off), w1 = *reinterpret_cast<const ulonglong2 *>(k1 + off);
+                // words outside [0, q) (bit-flipped inputs, reliability_test/dotprod_test.cu:38-61) take ONE cold branch; no calls on the hot path
+                if (__builtin_expect((cw.x >= p.q) | (cw.y >= p.q) | (w0.x >= p.q) | (w0.y >= p.q) | (w1.x >= p.q) | (w1.y >= p.q), 0)) {
+                    cw.x = barrett128(cw.x, 0, p.q, p.barrett_lo, p.barrett_hi);
+                    cw.y = barrett128(cw.y, 0, p.q, p.barrett_lo, p.barrett_hi);
+                    w0.x = barrett128(w0.x, 0, p.q, p.barrett_lo, p.barrett_hi);
+                    w0.y = barrett128(w0.y, 0, p.q, p.barrett_lo, p.barrett_hi);
+                    w1.x = barrett128(w1.x, 0, p.q, p.barrett_lo, p.barrett_hi);
+                    w1.y = barrett128(w1.y, 0, p.q, p.barrett_lo, p.barrett_hi);
+                }
+                elem x0, x1;
+                if (own) {
+                    x0 = A::from_canonical(cw.x);
+                    x1 = A::from_canonical(cw.y);
+                } else {
+                    const elem *src = lds + row * FR::ROW_LDS + row_pad(g);
+                    x0 = src[0];
+                    x1 = src[1];
+                }
+                const elem y00 = A::from_canonical(w0.x), y01 = A::from_canonical(w0.y), y10 = A::from_canonical(w1.x), y11 = A::from_canonical(w1.y);
+                if constexpr (A::PATH == PATH_F64) {
+                    A::lazy_acc(s0[k][0], A::mulvar_lazy(x0, y00, ctx), terms, ctx);
+                    A::lazy_acc(s0[k][1], A::mulvar_lazy(x1, y01, ctx), terms, ctx);
+                    A::lazy_acc(s1[k][0], A::mulvar_lazy(x0, y10, ctx), terms, ctx);
+                    A::lazy_acc(s1[k][1], A::mulvar_lazy(x1, y11, ctx), terms, ctx);
+                } else {
+                    A::lazy_acc(s0[k][0], A::mulvar_lazy(x0, y00, p), terms, ctx);
+                    A::lazy_acc(s0[k][1], A::mulvar_lazy(x1, y01, p), terms, ctx);
+                    A::lazy_acc(s1[k][0], A::mulvar_lazy(x0, y10, p), terms, ctx);
+                    A::lazy_acc(s1[k][1], A::mulvar_lazy(x1, y11, p), terms, ctx);
+                }
+            }
+#if defined(__HIP_DEVICE_COMPILE__)
+            if (k & 1) __builtin_amdgcn_sched_barrier(0);      // keep at most two pairs' loads in flight: the sums already hold 64 registers
+#endif
+        }
+    }
+    u64 *o0 = a.acc + ((size_t)jj << LOGN) + toff, *o1 = o0 + ((size_t)a.M << LOGN);
+#pragma unroll
+    for (int k = 0; k < PER; k++) {
+        const int i = tid + k * NTT_THREADS;
+        if (PAIRS % NTT_THREADS == 0 || i < PAIRS) {
+            const u32 row = (u32)i / (FR::NPTS / 2), g = ((u32)i % (FR::NPTS / 2)) * 2;
+            const size_t off = (size_t)row * FR::NPTS + g;
+            ulonglong2 r0, r1;
+            r0.x = A::canonical(s0[k][0], ctx);
+            r0.y = A::canonical(s0[k][1], ctx);
+            r1.x = A::canonical(s1[k][0], ctx);
+            r1.y = A::canonical(s1[k][1], ctx);
+            *reinterpret_cast<ulonglong2 *>(o0 + off) = r0;
+            *reinterpret_cast<ulonglong2 *>(o1 + off) = r1;
+        }
+    }
+}
+
+bool ks_rowmac_supported(int logn) { return logn >= 5 && logn <= NTT_MAX_LOGN; }
+
+template <class A, int LOGN>
+static void launch_rowmac_t(hipStream_t st, const KsMacArgs &a)
+{
+    constexpr int GEO = LOGN >= 13 ? 1 : 0;
+    typedef typename MidPasses<A, LOGN, GEO>::Fwd FR;
+    hipLaunchKernelGGL((k_ks_rowmac<A, LOGN, GEO>), dim3(a.M * FR::TILES), dim3(NTT_THREADS), 0, st, a);
+}
+
+hipError_t launch_ks_rowmac(hipStream_t st, const KsMacArgs &a, bool has_f64, bool has_u64)
+{
+    if (!a.M) return hipSuccess;
+    if (!ks_rowmac_supported(a.logn)) return hipErrorInvalidValue;
+    switch (a.logn) {
+#define FHE_CASE(L)                                              \
+    case L:                                                      \
+        if (has_f64) launch_rowmac_t<ArithF64, L>(st, a);        \
+        if (has_u64) launch_rowmac_t<ArithU64, L>(st, a);        \
+        break;
+        FHE_CASE(5) FHE_CASE(6) FHE_CASE(7) FHE_CASE(8) FHE_CASE(9) FHE_CASE(10) FHE_CASE(11) FHE_CASE(12) FHE_CASE(13)
+        FHE_CASE(14) FHE_CASE(15) FHE_CASE(16) FHE_CASE(17) FHE_CASE(18) FHE_CASE(19) FHE_CASE(20)
+#undef FHE_CASE
+    default:
+        return hipErrorInvalidValue;
+    }
+    return hipGetLastError();
+}
+
 // true when launch_ntt would use PassArgs::scratch for this transform (the caller then provides packed_scratch_words per unit)
 bool ntt_packed_supported(int logn, bool inverse, int path)
 {

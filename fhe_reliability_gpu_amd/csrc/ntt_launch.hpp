@@ -149,6 +149,12 @@ struct KsMacArgs {
     u32 cn, clo, sp_shift;
 };
 hipError_t launch_ks_mac(hipStream_t st, const KsMacArgs &a);
+// The same inner product with the LAST pass of the extended limbs' forward transform fused in (ntt_kernels.hip k_ks_rowmac):
+// `ext` then holds what the transform's first launch left (the column pass's lazy words; for single-pass sizes the
+// base-extension output itself), one workgroup per (owned limb, row tile) runs the row pass of every digit's limb in LDS,
+// multiplies by the two key halves and keeps the sums in registers: the transformed digits are never written or re-read.
+bool ks_rowmac_supported(int logn);
+hipError_t launch_ks_rowmac(hipStream_t st, const KsMacArgs &a, bool has_f64, bool has_u64);
 hipError_t launch_bconv_fast(hipStream_t st, u64 *out, const u64 *in, const BaseConvPlanDev &pl, u64 N);
 hipError_t launch_crt_garner(hipStream_t st, u64 *x_lo, u64 *x_hi, const u64 *residues, const u64 *moduli,
                              const u64 *ratios, const u64 *pref_lo, const u64 *pref_hi, const u64 *inv_pref, int m, u64 N);

@@ -72,8 +72,9 @@ def sharded_base_conversion(eng, local_in, mod_in: Sequence[int], mod_out: Seque
         plan = BaseConv(eng, mod_in, list(mod_out[lo:hi]))
         stream = C.c_void_p(torch.cuda.current_stream().cuda_stream)
         f = lib.fhe_baseconv_exact if exact else lib.fhe_baseconv_fast
+        torch.cuda.current_stream().synchronize()       # the gathered input is complete (a NULL handle below = the engine's own stream)
         check(f(eng._h, C.c_void_p(out.data_ptr()), C.c_void_p(full.data_ptr()), plan._h, n, stream))
-        torch.cuda.current_stream().synchronize()
+        eng.sync(stream if stream.value else None)
     return out
 
 
@@ -162,6 +163,29 @@ class ShardedKeySwitch:
                                                C.c_void_p(self.g2.data_ptr()), C.byref(h)))
         self._h = h
         self.rows1, self.rows2 = self.lay["cmax"], 2 * self.lay["smax"]
+        self._side = None
+
+    def stream_scope(self):
+        """The library takes a NULL stream handle to mean the engine's own (non-blocking) stream, which torch's legacy
+        default stream does not order against.  When the caller is on that default stream, the phases and the collectives
+        run on a side stream of the plan, fenced against the default stream at both ends."""
+        import contextlib
+
+        import torch
+        cur = torch.cuda.current_stream()
+        if cur.cuda_stream != 0:
+            return contextlib.nullcontext()
+        if self._side is None:
+            self._side = torch.cuda.Stream()
+        side = self._side
+
+        @contextlib.contextmanager
+        def scope():
+            side.wait_stream(cur)
+            with torch.cuda.stream(side):
+                yield
+            cur.wait_stream(side)
+        return scope()
 
     @staticmethod
     def _p(x):
@@ -213,6 +237,12 @@ def sharded_keyswitch(plan, c_local, evk_local, add0=None, add1=None, timings=No
     add0/add1 : optional [cn, N] terms added to the two output parts (rotation: sigma(c0); relinearisation: d0, d1)
     Returns this rank's ciphertext limbs of the two output parts.  ``timings`` (a dict) receives per-phase CUDA events
     when given: compute phases and the two joins are then reported separately (bench.py's strong-scaling leg)."""
+    import contextlib
+    with (plan.stream_scope() if hasattr(plan, "stream_scope") else contextlib.nullcontext()):
+        return _sharded_keyswitch(plan, c_local, evk_local, add0, add1, timings)
+
+
+def _sharded_keyswitch(plan, c_local, evk_local, add0, add1, timings):
     ev = None
     if timings is not None:
         import torch
@@ -245,12 +275,13 @@ def sharded_rotate(plan, c0_local, c1_local, galois_elt: int, gk_local, timings=
     import torch
 
     from ._lib import check, lib
-    s0, s1 = torch.empty_like(c0_local), torch.empty_like(c1_local)
-    st = C.c_void_p(torch.cuda.current_stream().cuda_stream)
-    if c0_local.shape[0]:
-        check(lib.fhe_automorphism_ntt(plan.eng._h, C.c_void_p(s0.data_ptr()), C.c_void_p(c0_local.data_ptr()), plan.t.log_n, galois_elt, c0_local.shape[0], st))
-        check(lib.fhe_automorphism_ntt(plan.eng._h, C.c_void_p(s1.data_ptr()), C.c_void_p(c1_local.data_ptr()), plan.t.log_n, galois_elt, c1_local.shape[0], st))
-    return sharded_keyswitch(plan, s1, gk_local, add0=s0, timings=timings)
+    with plan.stream_scope():
+        s0, s1 = torch.empty_like(c0_local), torch.empty_like(c1_local)
+        st = C.c_void_p(torch.cuda.current_stream().cuda_stream)
+        if c0_local.shape[0]:
+            check(lib.fhe_automorphism_ntt(plan.eng._h, C.c_void_p(s0.data_ptr()), C.c_void_p(c0_local.data_ptr()), plan.t.log_n, galois_elt, c0_local.shape[0], st))
+            check(lib.fhe_automorphism_ntt(plan.eng._h, C.c_void_p(s1.data_ptr()), C.c_void_p(c1_local.data_ptr()), plan.t.log_n, galois_elt, c1_local.shape[0], st))
+        return sharded_keyswitch(plan, s1, gk_local, add0=s0, timings=timings)
 
 
 def own_ct_rows(lay) -> List[int]:
