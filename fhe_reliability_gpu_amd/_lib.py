@@ -84,6 +84,8 @@ _SIG = {
     "fhe_abft_checksum": (ci, [vp, vp, ci, vp, vp, sz, sz, sz, vp]),
     "fhe_ntt_forward_checked": (ci, [vp, vp, vp, vp, sz, sz, sz, vp, vp]),
     "fhe_ctx_inject_fault": (ci, [vp, C.c_longlong, ci]),
+    "fhe_ntt_forward_checked_phases": (ci, [vp, vp, vp, vp, sz, sz, sz, vp, vp]),
+    "fhe_ctx_inject_fault_in_pass": (ci, [vp, ci, C.c_uint32, C.c_uint32, ci]),
     "fhe_automorphism": (ci, [vp, vp, vp, vp, C.c_uint32, sz, sz, sz, vp]),
     "fhe_automorphism_ntt": (ci, [vp, vp, vp, ci, C.c_uint32, sz, vp]),
     "fhe_keyswitch_create": (ci, [vp, vp, ci, ci, ci, C.POINTER(vp)]),

@@ -705,6 +705,34 @@ hipError_t launch_compare_sums(hipStream_t st, u32 *flags, const u64 *a, u32 ta,
     return hipGetLastError();
 }
 
+__global__ void k_compare_phases(u32 *flags, const u64 *s_in, const u64 *s_mid1, u32 tc, const u64 *s_mid2, const u64 *s_out, u32 tr, const LimbParams *lp,
+                                 u32 limb0, u32 limbs, u32 units)
+{
+    const u32 i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= units) return;
+    const u64 q = lp[limb0 + i % limbs].q;
+    auto total = [&](const u64 *v, u32 n) {
+        u64 s = 0;
+        for (u32 t = 0; t < n; t++) {
+            s += v[(u64)i * n + t];
+            s = s >= q ? s - q : s;
+        }
+        return s;
+    };
+    const u64 a = total(s_in, tc), b = total(s_mid1, tc), c = total(s_mid2, tr), d = total(s_out, tr);
+    flags[3 * i] = a != b;
+    flags[3 * i + 1] = b != c;
+    flags[3 * i + 2] = c != d;
+}
+
+hipError_t launch_compare_phases(hipStream_t st, u32 *flags, const u64 *s_in, const u64 *s_mid1, u32 tc, const u64 *s_mid2, const u64 *s_out, u32 tr,
+                                 const LimbParams *lp, u32 limb0, u32 limbs, u32 units)
+{
+    if (!units) return hipSuccess;
+    hipLaunchKernelGGL(k_compare_phases, dim3((units + 255) / 256), dim3(256), 0, st, flags, s_in, s_mid1, tc, s_mid2, s_out, tr, lp, limb0, limbs, units);
+    return hipGetLastError();
+}
+
 hipError_t launch_compare_flags(hipStream_t st, u32 *flags, const u64 *a, const u64 *b, u32 units)
 {
     if (!units) return hipSuccess;

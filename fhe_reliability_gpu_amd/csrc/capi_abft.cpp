@@ -12,6 +12,16 @@ int fhe_ctx_inject_fault(fhe_ctx *ctx, long long idx, int bit)
     return FHE_OK;
 }
 
+int fhe_ctx_inject_fault_in_pass(fhe_ctx *ctx, int pass, uint32_t workgroup, uint32_t lds_word, int bit)
+{
+    if (!ctx || bit < 0 || bit > 63 || pass > 1) return fail(FHE_ERR_INVALID, "bad fault");
+    ctx->pfault_pass = pass < 0 ? -1 : pass;
+    ctx->pfault_block = workgroup;
+    ctx->pfault_word = lds_word;
+    ctx->pfault_bit = bit;
+    return FHE_OK;
+}
+
 int fhe_abft_create(fhe_ctx *ctx, const fhe_ntt_tables *t, fhe_abft **out)
 {
     if (!ctx || !t || !out) return fail(FHE_ERR_INVALID, "null argument");
@@ -57,6 +67,48 @@ int fhe_abft_create(fhe_ctx *ctx, const fhe_ntt_tables *t, fhe_abft **out)
         HIP_TRY(a->win.upload(ein));
         HIP_TRY(a->wout.upload(eout));
         HIP_TRY(a->wout8.upload(out8));
+    }
+    if (ntt_phases_supported(t->log_n)) {
+        // Per-phase detector: weights on the words the column pass hands to the row pass.  The column pass is the same
+        // length-2^PC negacyclic transform C (root phi = psi^(2^PR), bit-reversed output) on every column, so
+        // u = P1^-T w has columns C^-T w_c = 2^-PC * NTT_{phi^-1}(w_c), and NTT_{phi^-1} is NTT_phi read at the
+        // complemented position: u[k][c] = 2^-PC * (column pass of w)[~k][c].  The device's own column pass produces it.
+        DevBuf wb;
+        HIP_TRY(wb.upload(w));
+        hipStream_t st = ctx->stream;
+        rc = for_each_run(t, t->count, 0, [&](size_t off, size_t len, int path) -> int {
+            PassArgs pa{wb.as<u64>() + off * N, t->d_lp.as<LimbParams>(), (u32)off, (u32)len, (u32)len, (u32)t->count};
+            hipError_t e = launch_ntt(st, pa, t->log_n, false, path, 1, 0);
+            return e == hipSuccess ? FHE_OK : hip_fail(e, "launch_ntt(column pass of the weights)");
+        });
+        if (rc) return rc;
+        HIP_TRY(hipStreamSynchronize(st));
+        std::vector<u64> y(w.size());
+        HIP_TRY(hipMemcpy(y.data(), wb.p, y.size() * 8, hipMemcpyDeviceToHost));
+        const int pc = ntt_column_stages(t->log_n), pr = t->log_n - pc;
+        const size_t n1 = (size_t)1 << pc, n2 = (size_t)1 << pr;
+        std::vector<Tw> eu(w.size());
+        std::vector<u64> u8(w.size());
+        for (int l = 0; l < t->count; l++) {
+            const u64 q = t->q[l], n1inv = host::inv_mod((u64)(n1 % q), q);
+            for (size_t k = 0; k < n1; k++)
+                for (size_t c = 0; c < n2; c++) {
+                    const u64 raw = y[(size_t)l * N + (n1 - 1 - k) * n2 + c];
+                    u64 v;
+                    if (t->path[l] == PATH_F64) {          // the hand-off holds raw FP64 bits of an exact integer in the lazy range
+                        const long long sv = (long long)u64_bits_to_double(raw);
+                        v = (u64)(((sv % (long long)q) + (long long)q) % (long long)q);
+                    } else {
+                        v = raw % q;                       // [0, 4q)
+                    }
+                    v = host::mul_mod(v, n1inv, q);
+                    const size_t idx = (size_t)l * N + k * n2 + c;
+                    eu[idx] = t->path[l] == PATH_F64 ? ArithF64::encode(v, q) : ArithU64::encode(v, q);
+                    u8[idx] = v;
+                }
+        }
+        HIP_TRY(a->umid.upload(eu));
+        HIP_TRY(a->umid8.upload(u8));
     }
     *out = a.release();
     return FHE_OK;
@@ -143,6 +195,59 @@ int fhe_ntt_forward_checked(fhe_ctx *ctx, uint64_t *d_data, const fhe_ntt_tables
     if ((rc = fhe_abft_checksum(ctx, a, 1, d_data, m->sum_out.as<u64>(), n_poly, limbs, start_idx, st))) return rc;
     hipError_t e = launch_compare_flags(st, d_flags, m->sum_in.as<u64>(), m->sum_out.as<u64>(), (u32)units);
     if (e != hipSuccess) return hip_fail(e, "launch_compare_flags");
+    return FHE_OK;
+}
+
+int fhe_ntt_forward_checked_phases(fhe_ctx *ctx, uint64_t *d_data, const fhe_ntt_tables *t, const fhe_abft *a, size_t n_poly, size_t limbs,
+                                   size_t start_idx, uint32_t *d_flags, void *stream)
+{
+    if (!ctx || !a || a->t != t || !d_flags || !d_data) return fail(FHE_ERR_INVALID, "bad checked-transform arguments");
+    if (!ntt_phases_supported(t->log_n) || ctx->mode != 0)
+        return fail(FHE_ERR_UNSUPPORTED, "per-phase checks belong to the two-launch transform (N >= 2^13); single-launch sizes have one phase: use fhe_ntt_forward_checked");
+    int rc = check_range(t, n_poly, limbs, start_idx);
+    if (rc) return rc;
+    const size_t units = n_poly * limbs, N = (size_t)1 << t->log_n;
+    if (!units) return FHE_OK;
+    fhe_abft *m = const_cast<fhe_abft *>(a);
+    HIP_TRY(hipSetDevice(ctx->device));
+    hipStream_t st = pick(ctx, stream);
+    u32 tc = 1, tr = 1;
+    ntt_checked_tiles(t->log_n, &tc, &tr);
+    if (m->sum_in.bytes < units * 8 * tc || m->sum_out.bytes < units * 8 * tr || m->sum_mid1.bytes < units * 8 * tc || m->sum_mid2.bytes < units * 8 * tr) {
+        HIP_TRY(hipStreamSynchronize(st));
+        HIP_TRY(m->sum_in.alloc(units * 16 * tc));
+        HIP_TRY(m->sum_mid1.alloc(units * 16 * tc));
+        HIP_TRY(m->sum_mid2.alloc(units * 16 * tr));
+        HIP_TRY(m->sum_out.alloc(units * 16 * tr));
+    }
+    // one-shot test hooks: a flip between the launches (fhe_ctx_inject_fault) and / or inside one pass (fhe_ctx_inject_fault_in_pass)
+    const bool between = ctx->fault_idx >= 0;
+    const int fpass = ctx->pfault_pass;
+    auto run = [&](int which) -> int {
+        return for_each_run(t, limbs, start_idx, [&](size_t off, size_t len, int path) -> int {
+            PassArgs pa{d_data + off * N, t->d_lp.as<LimbParams>(), (u32)(start_idx + off), (u32)len, (u32)(n_poly * len), (u32)limbs, nullptr};
+            PhaseArgs p1{a->win.as<Tw>(), a->umid.as<Tw>(), a->wout.as<Tw>(), a->umid8.as<u64>(), a->wout8.as<u64>(), t->log_n / 2,
+                         m->sum_in.as<u64>() + off * tc, m->sum_mid1.as<u64>() + off * tc, fpass, ctx->pfault_block, ctx->pfault_word, ctx->pfault_bit};
+            PhaseArgs p2 = p1;
+            p2.sum_a = m->sum_mid2.as<u64>() + off * tr;
+            p2.sum_b = m->sum_out.as<u64>() + off * tr;
+            hipError_t e = launch_ntt_phases(st, pa, p1, p2, t->log_n, path, which);
+            return e == hipSuccess ? FHE_OK : hip_fail(e, "launch_ntt_phases");
+        });
+    };
+    if (between) {
+        if ((rc = run(0))) return rc;
+        hipError_t e = launch_flip_bit(st, d_data, (u64)ctx->fault_idx, ctx->fault_bit);
+        if (e != hipSuccess) return hip_fail(e, "launch_flip_bit");
+        ctx->fault_idx = -1;
+        if ((rc = run(1))) return rc;
+    } else if ((rc = run(-1))) {
+        return rc;
+    }
+    ctx->pfault_pass = -1;
+    hipError_t e = launch_compare_phases(st, d_flags, m->sum_in.as<u64>(), m->sum_mid1.as<u64>(), tc, m->sum_mid2.as<u64>(), m->sum_out.as<u64>(), tr,
+                                         t->d_lp.as<LimbParams>(), (u32)start_idx, (u32)limbs, (u32)units);
+    if (e != hipSuccess) return hip_fail(e, "launch_compare_phases");
     return FHE_OK;
 }
 

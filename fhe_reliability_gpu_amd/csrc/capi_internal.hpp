@@ -104,6 +104,8 @@ struct fhe_ctx {
     std::string trace;          // collected trace text (fhe_ctx_trace)
     long long fault_idx = -1;   // one-shot mid-transform bit flip (fhe_ctx_inject_fault)
     int fault_bit = 0;
+    int pfault_pass = -1, pfault_bit = 0;       // one-shot bit flip INSIDE a pass of the per-phase checked transform
+    u32 pfault_block = 0, pfault_word = 0;      // (fhe_ctx_inject_fault_in_pass): workgroup and LDS word
     int geo = 1;           // column-tile geometry of the two-launch path (ntt_launch.hpp)
     bool resident = false; // 2^13 / 2^14: one LDS-resident pass instead of two launches (opt-in, see ntt_plan.hpp)
     int ks_fused = -1;     // key-switch inner product fused with the extended limbs' row pass: -1 = by shape, 0 = never, 1 = always (where supported)
@@ -121,6 +123,8 @@ struct fhe_abft {
     DevBuf win, wout, wout8;    // weights for the fused checksums: twiddle-encoded (ArithU64 limbs) and, for the output side,
                                 // as residues (ArithF64 limbs); N^-1 is folded into the output-side weights
     DevBuf sum_in, sum_out;     // scratch checksums (grown on demand)
+    DevBuf umid, umid8;         // per-phase detector: weights on the hand-off between the two launches, u = P1^-T w (twiddle-encoded / residues)
+    DevBuf sum_mid1, sum_mid2;  // hand-off checksums as stored by the column pass / as loaded by the row pass
 };
 
 // Which limbs a rank of a limb-sharded key switch owns: ciphertext limbs [clo, clo + cn) and special limbs

@@ -189,6 +189,7 @@ template <class P> FHE_HD u64 pk_extract(P w, u32 idx)
 // that checking a transform costs arithmetic only, not two more sweeps over the data.
 struct NoTap {
     static constexpr bool ACTIVE = false;
+    static constexpr bool MID = false;    // MID: the tap also sees the lazy words a column pass hands to the next launch
 };
 
 // ---------------------------------------------------------------------------
@@ -262,6 +263,12 @@ struct ColPass {
             if (INVERSE) radix_inv<A, K, RED, U0, SBLK, FOLD>(x, tw, S0 + DONE, prefix, c, &inv_n);
             else radix_fwd<A, K, RED, U0, SBLK>(x, tw, S0 + DONE, prefix, c);
             if (LAST) {
+                if constexpr (TAP::ACTIVE) {
+                    if constexpr (TAP::MID) {
+#pragma unroll
+                        for (int r = 0; r < R; r++) tap->mid((g0 + ((u32)r << LOGS)) * STRIDE + col, x[r], c);
+                    }
+                }
 #pragma unroll
                 for (int r = 0; r < R; r++) {
                     u64 *dst = base + (size_t)(g0 + ((u32)r << LOGS)) * STRIDE + col;

@@ -220,6 +220,7 @@ struct AbftArgs {
 template <class A, bool IN, bool OUT>
 struct ChecksumTap {
     static constexpr bool ACTIVE = true;
+    static constexpr bool MID = false;
     typedef typename A::elem elem;
     TwPtr win, wout;                   // ArithU64: Shoup-encoded weights of this limb, offset to the tile's first element
     const u64 FHE_GLOBAL *wout8;       // ArithF64: output-side weights as plain residues (the quotient factor is one multiply)
@@ -251,6 +252,52 @@ struct ChecksumTap {
             }
         }
     }
+};
+
+// Per-phase detector (the reference checks its four-step flow phase by phase: batch_check of the column transforms,
+// check_inter around the twiddle step, batch_check of the row transforms -- rfhe_framewk/src/ntt_test/relia_ntt_sim.cpp:235-292,
+// 331-355; reliability_test/four_step_ntt_prot.py:185-194).  The engine's two launches ARE that flow -- column transforms,
+// then row transforms with the twiddle folded into their butterflies -- so the checks sit at the same three places:
+//   column pass :  sum_i w_i x_i  (words it loads)        ==  sum_i u_i y_i  (words it stores),   u = P1^-T w
+//   hand-off    :  sum_i u_i y_i  (as stored)             ==  sum_i u_i y_i  (as loaded by the row pass)
+//   row pass    :  sum_i u_i y_i  (words it loads)        ==  sum_j w^_j X_j (words it stores),   w^ = T^-T w
+// PASS 0 = column pass (in: w, mid: u), PASS 1 = row pass (in: u, out: w^).
+template <class A, int PASS>
+struct PhaseTap {
+    static constexpr bool ACTIVE = true;
+    static constexpr bool MID = PASS == 0;
+    typedef typename A::elem elem;
+    TwPtr win, umid, wout;             // ArithU64: Shoup-encoded weights of this limb, offset to the tile's first element
+    const u64 FHE_GLOBAL *umid8, *wout8;   // ArithF64: the same weights as plain residues
+    u32 pos0;
+    int logp;
+    elem acc_a, acc_b;
+    int n_a, n_b;
+    FHE_D void weigh(elem &acc, int &n, elem x, u32 idx, TwPtr tw, const u64 FHE_GLOBAL *tw8, const typename A::Ctx &c)
+    {
+        if constexpr (A::PATH == PATH_F64) {
+            const double w = A::from_canonical(tw8[idx]);
+            A::lazy_acc(acc, A::mulmod_w(x, w, w * c.ninv, c), ++n, c);
+        } else {
+            A::lazy_acc(acc, A::mulmod(x, tw[idx], c), ++n, c);
+        }
+    }
+    FHE_D void in(u32 idx, elem x, const typename A::Ctx &c)
+    {
+        if constexpr (PASS == 0) {
+            if constexpr (A::PATH == PATH_F64) {
+                const u32 i = pos0 + idx;
+                const double w = (double)((i & ((1u << logp) - 1u)) + (i >> logp) + 2u);     // generate_weights, negaclic_ntt.py:7-13
+                A::lazy_acc(acc_a, A::mulmod_w(x, w, w * c.ninv, c), ++n_a, c);
+            } else {
+                A::lazy_acc(acc_a, A::mulmod(x, win[idx], c), ++n_a, c);
+            }
+        } else {
+            weigh(acc_a, n_a, x, idx, umid, umid8, c);
+        }
+    }
+    FHE_D void mid(u32 idx, elem x, const typename A::Ctx &c) { weigh(acc_b, n_b, x, idx, umid, umid8, c); }
+    FHE_D void out(u32 idx, u64 v, const typename A::Ctx &c) { weigh(acc_b, n_b, A::from_canonical(v), idx, wout, wout8, c); }
 };
 
 // modular sum of one canonical value per thread over the workgroup, stored to *dst by one lane
@@ -327,6 +374,88 @@ static hipError_t launch_checked(hipStream_t st, const PassArgs &a, const AbftAr
         if (which != 0) hipLaunchKernelGGL((k_ntt_pass_abft<typename PS::Row, LOGN, false, false, true>), dim3(a.units * PS::Row::TILES), dim3(NTT_THREADS), 0, st, a, ab);
     }
     return hipGetLastError();
+}
+
+// ---- per-phase variant (two-launch sizes) ----
+template <class PASS, int LOGN, bool IS_COL, int PASSID>
+__global__ __launch_bounds__(NTT_THREADS) void k_ntt_pass_phase(PassArgs a, PhaseArgs ph)
+{
+    typedef typename PASS::Arith A;
+    static_assert(PASS::NPHASE >= 2, "per-phase checks are for the two-launch sizes");
+    __shared__ __attribute__((aligned(16))) typename PASS::elem lds[PASS::LDS_ELEMS];
+    __shared__ u64 red[2][NTT_THREADS / 64];
+    u32 limb, row0 = 0;
+    u64 *base;
+    if constexpr (IS_COL) base = col_tile<PASS, LOGN>(blockIdx.x, a, limb);
+    else base = row_tile<PASS, LOGN>(blockIdx.x, a, limb, row0);
+    const u32 unit = blockIdx.x / PASS::TILES, polys = a.units / a.limbs;
+    const u32 l = unit / polys, poly = unit % polys, slot = poly * a.poly_stride + l;
+    const u32 pos0 = (u32)((base - a.data) & (((size_t)1 << LOGN) - 1));
+    const LimbParams &p = a.lp[limb];
+    const typename A::Ctx ctx = A::make_ctx(p);
+    const TwPtr tw = as_global(p.fwd);
+    const Tw inv_n = p.inv_n;
+    const int tid = threadIdx.x;
+    const size_t woff = ((size_t)limb << LOGN) + pos0;
+    PhaseTap<A, PASSID> tap{as_global(ph.win) + woff, as_global(ph.umid) + woff, as_global(ph.wout) + woff, (const u64 FHE_GLOBAL *)ph.umid8 + woff,
+                            (const u64 FHE_GLOBAL *)ph.wout8 + woff, pos0, ph.logp, typename A::elem(0), typename A::elem(0), 0, 0};
+    PASS::template phase<0>(tid, base, lds, tw, row0, ctx, inv_n, &tap);
+    __syncthreads();
+    // test hook: a soft error INSIDE this pass -- one bit of one word of the LDS image between two register steps
+    if (ph.fault_pass == PASSID && ph.fault_block == blockIdx.x) {
+        if (tid == 0) reinterpret_cast<u64 *>(lds)[ph.fault_word % (u32)PASS::LDS_ELEMS] ^= (u64)1 << ph.fault_bit;
+        __syncthreads();
+    }
+    PASS::template phase<1>(tid, base, lds, tw, row0, ctx, inv_n, &tap);
+    if constexpr (PASS::NPHASE > 2) {
+        __syncthreads();
+        PASS::template phase<2>(tid, base, lds, tw, row0, ctx, inv_n, &tap);
+    }
+    if constexpr (PASS::NPHASE > 3) {
+        __syncthreads();
+        PASS::template phase<3>(tid, base, lds, tw, row0, ctx, inv_n, &tap);
+    }
+    const u32 tile = blockIdx.x % PASS::TILES;
+    block_sum_mod(A::canonical(tap.acc_a, ctx), p.q, ph.sum_a + (size_t)slot * PASS::TILES + tile, red[0]);
+    block_sum_mod(A::canonical(tap.acc_b, ctx), p.q, ph.sum_b + (size_t)slot * PASS::TILES + tile, red[1]);
+}
+
+template <class A, int LOGN>
+static hipError_t launch_phases_t(hipStream_t st, const PassArgs &a, const PhaseArgs &p1, const PhaseArgs &p2, int which)
+{
+    typedef Passes<A, LOGN, false, 1> PS;
+    if constexpr (PS::G::TWO_PASS) {
+        if (which != 1) hipLaunchKernelGGL((k_ntt_pass_phase<typename PS::Col, LOGN, true, 0>), dim3(a.units * PS::Col::TILES), dim3(NTT_THREADS), 0, st, a, p1);
+        if (which != 0) hipLaunchKernelGGL((k_ntt_pass_phase<typename PS::Row, LOGN, false, 1>), dim3(a.units * PS::Row::TILES), dim3(NTT_THREADS), 0, st, a, p2);
+        return hipGetLastError();
+    }
+    return hipErrorInvalidValue;
+}
+
+bool ntt_phases_supported(int logn) { return logn >= 13 && logn <= NTT_MAX_LOGN; }
+
+int ntt_column_stages(int logn)
+{
+    switch (logn) {
+#define FHE_CASE(L) case L: return Plan<L>::Col::P;
+        FHE_CASE(1) FHE_CASE(2) FHE_CASE(3) FHE_CASE(4) FHE_CASE(5) FHE_CASE(6) FHE_CASE(7) FHE_CASE(8) FHE_CASE(9) FHE_CASE(10)
+        FHE_CASE(11) FHE_CASE(12) FHE_CASE(13) FHE_CASE(14) FHE_CASE(15) FHE_CASE(16) FHE_CASE(17) FHE_CASE(18) FHE_CASE(19) FHE_CASE(20)
+#undef FHE_CASE
+    default: return 0;
+    }
+}
+
+hipError_t launch_ntt_phases(hipStream_t st, const PassArgs &a, const PhaseArgs &p1, const PhaseArgs &p2, int logn, int path, int which)
+{
+    if (a.units == 0) return hipSuccess;
+    if (a.map || !ntt_phases_supported(logn)) return hipErrorInvalidValue;
+    switch (logn) {
+#define FHE_CASE(L) \
+    case L: return path == PATH_F64 ? launch_phases_t<ArithF64, L>(st, a, p1, p2, which) : launch_phases_t<ArithU64, L>(st, a, p1, p2, which);
+        FHE_CASE(13) FHE_CASE(14) FHE_CASE(15) FHE_CASE(16) FHE_CASE(17) FHE_CASE(18) FHE_CASE(19) FHE_CASE(20)
+#undef FHE_CASE
+    default: return hipErrorInvalidValue;
+    }
 }
 
 bool ntt_checked_supported(int logn) { return logn >= 5 && logn <= NTT_MAX_LOGN; }

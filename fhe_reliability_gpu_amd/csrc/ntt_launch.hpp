@@ -26,6 +26,27 @@ void ntt_checked_tiles(int logn, u32 *tin, u32 *tout);
 hipError_t launch_ntt_checked(hipStream_t st, const PassArgs &a, const Tw *win, const Tw *wout, const u64 *wout8, u64 *sum_in, u64 *sum_out,
                               int logn, int path, int which = -1);
 
+// per-phase detector (two-launch sizes): the column pass accumulates sum w x over what it loads and sum u y over what it
+// stores, the row pass sum u y over what it loads and sum w^ X over what it stores (weights: capi_abft.cpp).  One PhaseArgs
+// per launch; sum_a / sum_b = that launch's [units][tiles] partial sums.  fault_*: test hook, a bit flip in the LDS image of
+// workgroup fault_block of pass fault_pass between its first two phases (fault_pass < 0: off).
+struct PhaseArgs {
+    const Tw *win, *umid, *wout;
+    const u64 *umid8, *wout8;
+    int logp;
+    u64 *sum_a, *sum_b;
+    int fault_pass;
+    u32 fault_block, fault_word;
+    int fault_bit;
+};
+bool ntt_phases_supported(int logn);
+int ntt_column_stages(int logn);   // PC of the size's plan (0 for single-launch sizes)
+hipError_t launch_ntt_phases(hipStream_t st, const PassArgs &a, const PhaseArgs &p1, const PhaseArgs &p2, int logn, int path, int which = -1);
+// flags[unit*3 + {0,1,2}] = column pass / hand-off / row pass checks failed; s_in, s_mid1 have `tc` partial sums per unit,
+// s_mid2, s_out `tr`
+hipError_t launch_compare_phases(hipStream_t st, u32 *flags, const u64 *s_in, const u64 *s_mid1, u32 tc, const u64 *s_mid2, const u64 *s_out, u32 tr,
+                                 const LimbParams *lp, u32 limb0, u32 limbs, u32 units);
+
 // packed hand-off between the two launches (forward 2^16, FP64 limbs): when PassArgs::scratch is set (ntt_packed_scratch_words()
 // 64-bit words per unit) the intermediate travels as 50-bit residues in 16x16 blocks instead of 8-byte words in place
 bool ntt_packed_supported(int logn, bool inverse, int path);

@@ -501,6 +501,14 @@ class Abft:
         check(lib.fhe_ntt_forward_checked(self.eng._h, d.ptr, self.t._h, self._h, n_poly, limbs, start, flags.ptr, None))
         return flags.download().view(np.uint32)[: n_poly * limbs]
 
+    def forward_checked_phases(self, d: DeviceArray, n_poly: int = 1, limbs: Optional[int] = None, start: int = 0) -> np.ndarray:
+        """In-place forward NTT with the per-phase detector; returns flags[unit, 3] = (column pass, hand-off, row pass)."""
+        limbs = len(self.t) - start if limbs is None else limbs
+        n = n_poly * limbs * 3
+        flags = self.eng.alloc((n + 1) // 2)
+        check(lib.fhe_ntt_forward_checked_phases(self.eng._h, d.ptr, self.t._h, self._h, n_poly, limbs, start, flags.ptr, None))
+        return flags.download().view(np.uint32)[:n].reshape(n_poly * limbs, 3)
+
     def __del__(self):
         try:
             if self._h and self.eng._h:

@@ -299,6 +299,22 @@ int fhe_abft_checksum(fhe_ctx *ctx, const fhe_abft *a, int side, const uint64_t 
  * sweep over the data.  The detector object owns scratch: one call at a time per fhe_abft. */
 int fhe_ntt_forward_checked(fhe_ctx *ctx, uint64_t *d_data, const fhe_ntt_tables *t, const fhe_abft *a, size_t n_poly,
                             size_t limbs, size_t start_idx, uint32_t *d_flags, void *stream);
+/* The same detector phase by phase, where the reference checks its four-step flow: batch_check of the column transforms,
+ * check_inter around the twiddle step, batch_check of the row transforms (rfhe_framewk/src/ntt_test/relia_ntt_sim.cpp:235-292,
+ * 331-355; the per-multiply equality of reliability_test/four_step_ntt_prot.py:185-194).  The engine's two launches are that
+ * flow (column transforms; row transforms with the twiddle folded into their butterflies), so three flags per
+ * limb-polynomial, d_flags[3*unit + k]:
+ *   k = 0  column pass : sum w x over the words it loaded  !=  sum u y over the words it stored       (u = P1^-T w)
+ *   k = 1  hand-off    : sum u y as stored by the column pass  !=  as loaded by the row pass (corruption between the launches)
+ *   k = 2  row pass    : sum u y over the words it loaded  !=  sum w^ X over the words it stored
+ * A fault raises the flag of the phase it hit and no other.  Two-launch sizes (N >= 2^13); smaller transforms are one
+ * launch = one phase: fhe_ntt_forward_checked. */
+int fhe_ntt_forward_checked_phases(fhe_ctx *ctx, uint64_t *d_data, const fhe_ntt_tables *t, const fhe_abft *a, size_t n_poly,
+                                   size_t limbs, size_t start_idx, uint32_t *d_flags, void *stream);
+/* Test hook: a soft error INSIDE a pass of the next fhe_ntt_forward_checked_phases call -- XOR bit `bit` of word `lds_word`
+ * (modulo the image size) of workgroup `workgroup`'s LDS image between the pass's first two register steps; pass 0 = column
+ * pass, 1 = row pass, < 0 clears it.  One shot.  (The reference injects into butterfly results, relia_ntt_sim.cpp:189-194.) */
+int fhe_ctx_inject_fault_in_pass(fhe_ctx *ctx, int pass, uint32_t workgroup, uint32_t lds_word, int bit);
 /* Test hook for the detector: XOR bit `bit` of word `idx` of the buffer BETWEEN the two launches of the
  * next two-pass forward/inverse transform issued on this context (one shot; idx < 0 clears it).  This is
  * the in-flight analogue of the host-side flips of reliability_test/ntt_test.cu:104-135. */
