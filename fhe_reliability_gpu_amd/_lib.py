@@ -69,6 +69,7 @@ _SIG = {
     "fhe_fourstep_create": (ci, [vp, u64, u64, u64, u64, C.POINTER(vp)]),
     "fhe_fourstep_destroy": (ci, [vp]),
     "fhe_fourstep_ntt": (ci, [vp, vp, vp, vp, vp]),
+    "fhe_fourstep_ntt_batch": (ci, [vp, vp, vp, vp, sz, vp]),
     "fhe_modmul": (ci, [vp, vp, vp, vp, vp, sz, sz, sz, vp]),
     "fhe_modmul_acc": (ci, [vp, vp, vp, vp, vp, sz, sz, sz, vp]),
     "fhe_polymul": (ci, [vp, vp, vp, vp, vp, sz, sz, sz, vp]),

@@ -167,59 +167,6 @@ hipError_t launch_bitrev_scale(hipStream_t st, u64 *dst, const u64 *src, int log
     return hipGetLastError();
 }
 
-// out[c*rows + r] = in[r*cols + brev(c)] * tw[r*cols + c]
-__global__ __launch_bounds__(256) void k_fourstep_mid(u64 *out, const u64 *in, u32 rows, u32 cols, int log_cols,
-                                                      const u64 *tw, ModConst mc, bool with_twiddle)
-{
-    const u64 q = mc.q, r0 = mc.r0, r1 = mc.r1;
-    const u64 total = (u64)rows * cols;
-    for (u64 o = blockIdx.x * (u64)blockDim.x + threadIdx.x; o < total; o += (u64)gridDim.x * blockDim.x) {
-        const u32 c = (u32)(o / rows), r = (u32)(o % rows);
-        const u32 cb = log_cols ? (__brev(c) >> (32 - log_cols)) : 0;
-        u64 v = in[(u64)r * cols + cb];
-        if (with_twiddle) v = mulmod_b(v, tw[(u64)r * cols + c], q, r0, r1);
-        out[o] = v;
-    }
-}
-
-hipError_t launch_fourstep_mid(hipStream_t st, u64 *out, const u64 *in, u32 rows, u32 cols, int log_cols, const u64 *tw,
-                               const ModConst &mc, bool with_twiddle)
-{
-    const u64 total = (u64)rows * cols;
-    u64 want = (total + 255) / 256;
-    hipLaunchKernelGGL(k_fourstep_mid, dim3((u32)(want > 8192 ? 8192 : want)), dim3(256), 0, st, out, in, rows, cols,
-                       log_cols, tw, mc, with_twiddle);
-    return hipGetLastError();
-}
-
-// out[c][r] = in[r][c], 32x32 tiles through LDS (+1 padding against bank conflicts)
-__global__ __launch_bounds__(256) void k_transpose(u64 *out, const u64 *in, u32 rows, u32 cols)
-{
-    __shared__ u64 tile[32][33];
-    const u32 tx = threadIdx.x & 31, ty = threadIdx.x >> 5; // 32 x 8
-    const u32 tiles_c = (cols + 31) / 32, tiles_r = (rows + 31) / 32;
-    for (u32 t = blockIdx.x; t < tiles_c * tiles_r; t += gridDim.x) {
-        const u32 tr = t / tiles_c, tc = t % tiles_c;
-        for (u32 k = ty; k < 32; k += 8) {
-            const u32 r = tr * 32 + k, c = tc * 32 + tx;
-            if (r < rows && c < cols) tile[k][tx] = in[(u64)r * cols + c];
-        }
-        __syncthreads();
-        for (u32 k = ty; k < 32; k += 8) {
-            const u32 c = tc * 32 + k, r = tr * 32 + tx;
-            if (r < rows && c < cols) out[(u64)c * rows + r] = tile[tx][k];
-        }
-        __syncthreads();
-    }
-}
-
-hipError_t launch_transpose(hipStream_t st, u64 *out, const u64 *in, u32 rows, u32 cols)
-{
-    const u32 tiles = ((cols + 31) / 32) * ((rows + 31) / 32);
-    hipLaunchKernelGGL(k_transpose, dim3(tiles > 8192 ? 8192 : tiles), dim3(256), 0, st, out, in, rows, cols);
-    return hipGetLastError();
-}
-
 // ---------------------------------------------------------------------------
 // Base conversion.  One lane = one coefficient; residues are read at stride N
 // (coalesced across lanes), mixed-radix digits stay in registers.

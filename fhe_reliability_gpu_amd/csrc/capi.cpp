@@ -5,8 +5,12 @@
 #include "capi_internal.hpp"
 
 // Build device tables from forward tables in canonical residues (count x N).
+// gs_scale (optional, one per limb): "natural-order" table set for launch_ntt_gs -- the INVERSE slot receives the given rows
+// themselves (the inverse-structured network then computes the transposed transform: bit-reversed in, natural out, same
+// twiddles) with entry 0 = scale * rows[1] and inv_n = scale, so that the last stage multiplies the result by `scale`
+// (1 for a forward cyclic transform, n^-1 for motivation/bsgs.py:31-36's intt).  No twiddle needs an inverse: any modulus.
 int build_tables(fhe_ctx *ctx, int log_n, const u64 *q, int count, const u64 *fwd_rows, bool want_inverse, int force_path,
-                 const u64 *psi_or_null, fhe_ntt_tables **out)
+                 const u64 *psi_or_null, fhe_ntt_tables **out, const u64 *gs_scale)
 {
     if (!ctx || !q || !out || count < 1 || log_n < 1 || log_n > NTT_MAX_LOGN) return fail(FHE_ERR_INVALID, "bad table arguments");
     const size_t N = (size_t)1 << log_n;
@@ -32,8 +36,13 @@ int build_tables(fhe_ctx *ctx, int log_n, const u64 *q, int count, const u64 *fw
         Tw *f = tw.data() + (size_t)l * 2 * N, *b = f + N;
         for (size_t k = 0; k < N; k++) f[tw_stored_index(log_n, (u32)k)] = encode(path, row[k] % q[l], q[l]);
         bool inv_ok = false;
-        if (want_inverse) inv_ok = batch_inverse(row, N, q[l], inv);
-        if (inv_ok) {
+        if (gs_scale) {
+            const u64 sc = gs_scale[l] % q[l];
+            for (size_t k = 1; k < N; k++) b[tw_stored_index(log_n, (u32)k)] = encode(path, row[k] % q[l], q[l]);
+            b[tw_stored_index(log_n, 0)] = encode(path, host::mul_mod(sc, row[1 % N] % q[l], q[l]), q[l]);
+        } else if (want_inverse) inv_ok = batch_inverse(row, N, q[l], inv);
+        if (gs_scale) {
+        } else if (inv_ok) {
             // entry 0 is not a twiddle of the network: it carries N^-1 times the last inverse stage's twiddle (entry 1),
             // which that stage uses to scale while it multiplies (ntt_core.hpp radix_inv FOLD)
             inv[0] = host::mul_mod(host::inv_mod((u64)(N % q[l]), q[l]), inv[1 % N], q[l]);
@@ -48,7 +57,7 @@ int build_tables(fhe_ctx *ctx, int log_n, const u64 *q, int count, const u64 *fw
         p.two_q = 2 * q[l];
         p.n = (double)q[l];
         p.ninv = 1.0 / p.n;
-        const u64 ninv = host::inv_mod((u64)(N % q[l]), q[l]);
+        const u64 ninv = gs_scale ? gs_scale[l] % q[l] : host::inv_mod((u64)(N % q[l]), q[l]);
         if (!ninv && want_inverse) t->has_inverse = false;
         p.inv_n = encode(path, ninv, q[l]);
         p.fwd = t->d_tw.as<Tw>() + (size_t)l * 2 * N;
@@ -135,6 +144,55 @@ int pointwise(fhe_ctx *ctx, u64 *c, const u64 *a, const u64 *b, const fhe_ntt_ta
     PointwiseArgs p{c, a, b, t->d_lp.as<LimbParams>(), (u32)start_idx, (u32)limbs, (u32)(n_poly * limbs), (u32)limbs, t->log_n};
     hipError_t e = launch_modmul(pick(ctx, stream), p, acc);
     if (e != hipSuccess) return hip_fail(e, "launch_modmul");
+    return FHE_OK;
+}
+
+// natural-order table set (GS mode) of a cyclic transform, cached per context
+int cyclic_tables(fhe_ctx *ctx, int log_n, u64 mod, u64 root, int convention, u64 scale, fhe_ntt_tables **out)
+{
+    std::lock_guard<std::mutex> lock(ctx->mu);
+    auto key = std::make_tuple(log_n, mod, root, convention * 2 + 1, scale);
+    auto it = ctx->cyclic.find(key);
+    if (it == ctx->cyclic.end()) {
+        const u64 n = (u64)1 << log_n;
+        std::vector<u64> tw(n);
+        host::cyclic_table(mod, log_n, root, convention == 1, tw.data());
+        fhe_ntt_tables *nt = nullptr;
+        int rc = build_tables(ctx, log_n, &mod, 1, tw.data(), false, -1, nullptr, &nt, &scale);
+        if (rc) return rc;
+        it = ctx->cyclic.emplace(key, std::unique_ptr<fhe_ntt_tables>(nt)).first;
+    }
+    *out = it->second.get();
+    return FHE_OK;
+}
+
+// lengths below 2^5: the forward network with a cyclic table, then the bit-reversal gather (three tiny launches)
+static int cyclic_small(fhe_ctx *ctx, u64 *d_data, u64 *d_scratch, int log_n, size_t n_vec, u64 mod, u64 root, int convention, u64 scale, bool do_scale,
+                        void *stream)
+{
+    fhe_ntt_tables *t = nullptr;
+    {
+        std::lock_guard<std::mutex> lock(ctx->mu);
+        auto key = std::make_tuple(log_n, mod, root, convention * 2, (u64)0);
+        auto it = ctx->cyclic.find(key);
+        if (it == ctx->cyclic.end()) {
+            std::vector<u64> tw((size_t)1 << log_n);
+            host::cyclic_table(mod, log_n, root, convention == 1, tw.data());
+            fhe_ntt_tables *nt = nullptr;
+            int rc = build_tables(ctx, log_n, &mod, 1, tw.data(), false, -1, nullptr, &nt);
+            if (rc) return rc;
+            it = ctx->cyclic.emplace(key, std::unique_ptr<fhe_ntt_tables>(nt)).first;
+        }
+        t = it->second.get();
+    }
+    HIP_TRY(hipSetDevice(ctx->device));
+    hipStream_t st = pick(ctx, stream);
+    PassArgs a{d_data, t->d_lp.as<LimbParams>(), 0u, 1u, (u32)n_vec, 1u};
+    hipError_t e = launch_ntt(st, a, log_n, false, t->path[0]);
+    if (e != hipSuccess) return hip_fail(e, "launch_ntt(cyclic)");
+    e = launch_bitrev_scale(st, d_scratch, d_data, log_n, (u32)n_vec, mod_const(mod), scale, do_scale);
+    if (e != hipSuccess) return hip_fail(e, "launch_bitrev_scale");
+    HIP_TRY(hipMemcpyAsync(d_data, d_scratch, (n_vec << log_n) * sizeof(u64), hipMemcpyDeviceToDevice, st));
     return FHE_OK;
 }
 
@@ -401,78 +459,45 @@ int fhe_ntt_cyclic(fhe_ctx *ctx, uint64_t *d_data, uint64_t *d_scratch, int log_
         use_root = host::pow_mod(root, mod - 2, mod);
         scale = host::pow_mod(n % mod, mod - 2, mod);
     }
+    if (!ntt_gs_supported(log_n)) return cyclic_small(ctx, d_data, d_scratch, log_n, n_vec, mod, use_root, convention, scale, inverse != 0, stream);
     fhe_ntt_tables *t = nullptr;
-    {
-        std::lock_guard<std::mutex> lock(ctx->mu);
-        auto key = std::make_tuple(log_n, (u64)mod, use_root, convention);
-        auto it = ctx->cyclic.find(key);
-        if (it == ctx->cyclic.end()) {
-            std::vector<u64> tw(n);
-            host::cyclic_table(mod, log_n, use_root, convention == 1, tw.data());
-            fhe_ntt_tables *nt = nullptr;
-            u64 q = mod;
-            int rc = build_tables(ctx, log_n, &q, 1, tw.data(), false, -1, nullptr, &nt);
-            if (rc) return rc;
-            it = ctx->cyclic.emplace(key, std::unique_ptr<fhe_ntt_tables>(nt)).first;
-        }
-        t = it->second.get();
-    }
+    int rc = cyclic_tables(ctx, log_n, mod, use_root, convention, scale, &t);
+    if (rc) return rc;
     HIP_TRY(hipSetDevice(ctx->device));
     hipStream_t st = pick(ctx, stream);
+    // two launches, the bit reversal folded into the first one's loads, the scale into the last stage: d_data -> d_scratch -> d_data
     PassArgs a{d_data, t->d_lp.as<LimbParams>(), 0u, 1u, (u32)n_vec, 1u};
-    hipError_t e = launch_ntt(st, a, log_n, false, t->path[0]);
-    if (e != hipSuccess) return hip_fail(e, "launch_ntt(cyclic)");
-    e = launch_bitrev_scale(st, d_scratch, d_data, log_n, (u32)n_vec, mod_const(mod), scale, inverse != 0);
-    if (e != hipSuccess) return hip_fail(e, "launch_bitrev_scale");
-    HIP_TRY(hipMemcpyAsync(d_data, d_scratch, n_vec * n * sizeof(u64), hipMemcpyDeviceToDevice, st));
+    a.src = d_data;
+    hipError_t e = launch_ntt_gs(st, a, d_scratch, log_n, t->path[0]);
+    if (e != hipSuccess) return hip_fail(e, "launch_ntt_gs");
     return FHE_OK;
 }
 
 // ---------------------------------------------------------------- four-step
+// four_step_ntt (reliability_test/four_step_ntt_prot.py:71-109): column transforms, twiddle, row transforms, natural-order
+// output, equal to the direct DFT with w = g^((mod-1)/N) (:244-245).  The engine's natural-order transform IS that flow --
+// launch 1 = the batch of "column" transforms read straight from the input's columns (no transpose pass), launch 2 = the batch
+// of "row" transforms with the twiddle w^(k2 t1) folded into their butterflies, written in natural order -- at the engine's own
+// split of N (ntt_plan.hpp); the result does not depend on the split, so any power-of-two (n1, n2) is accepted, n1 != n2 included.
 int fhe_fourstep_create(fhe_ctx *ctx, uint64_t n1, uint64_t n2, uint64_t mod, uint64_t g, fhe_fourstep **out)
 {
     if (!ctx || !out) return fail(FHE_ERR_INVALID, "null argument");
     const int l1 = ilog2_exact(n1), l2 = ilog2_exact(n2);
-    if (l1 < 1 || l2 < 1 || l1 > NTT_MAX_LOGN || l2 > NTT_MAX_LOGN || l1 + l2 > 26 || mod < 2)
-        return fail(FHE_ERR_INVALID, "n1 and n2 must be powers of two >= 2");
+    if (l1 < 1 || l2 < 1 || l1 + l2 > NTT_MAX_LOGN || mod < 2) return fail(FHE_ERR_INVALID, "n1 and n2 must be powers of two >= 2 with n1 * n2 <= 2^20");
     const u64 N = n1 * n2;
     if ((mod - 1) % N) return fail(FHE_ERR_INVALID, "N must divide mod - 1");
+    if (mod >= ((u64)1 << 61)) return fail(FHE_ERR_UNSUPPORTED, "modulus must be below 2^61");
     std::unique_ptr<fhe_fourstep> p(new fhe_fourstep);
     p->ctx = ctx;
     p->n1 = n1;
     p->n2 = n2;
     p->mod = mod;
-    p->log1 = l1;
-    p->log2 = l2;
-    p->mc = mod_const(mod);
-    // sub-transforms: length n2 with root w^n1 and length n1 with root w^n2 are both
-    // "generator" transforms of g (four_step_ntt_prot.py:76-78): wlen(len) = g^((mod-1)/len)
-    std::vector<u64> tw2(n2), tw1(n1);
-    host::cyclic_table(mod, l2, g, false, tw2.data());
-    host::cyclic_table(mod, l1, g, false, tw1.data());
-    u64 q = mod;
-    int rc = build_tables(ctx, l2, &q, 1, tw2.data(), false, -1, nullptr, &p->t2);
-    if (rc) return rc;
-    rc = build_tables(ctx, l1, &q, 1, tw1.data(), false, -1, nullptr, &p->t1);
-    if (rc) {
-        fhe_ntt_tables_destroy(p->t2);
-        return rc;
+    p->g = g % mod;
+    p->log_n = l1 + l2;
+    if (ntt_gs_supported(p->log_n)) {
+        int rc = cyclic_tables(ctx, p->log_n, mod, p->g, 0, 1 % mod, &p->t);
+        if (rc) return rc;
     }
-    // C[t1][k2] = B[t1][k2] * w^(k2*t1)  (four_step_ntt_prot.py:93)
-    const u64 w = host::pow_mod(g, (mod - 1) / N, mod);
-    std::vector<u64> tw(N);
-    for (u64 t1 = 0; t1 < n1; t1++) {
-        const u64 step = host::pow_mod(w, t1, mod);
-        u64 cur = 1 % mod;
-        for (u64 k2 = 0; k2 < n2; k2++) {
-            tw[t1 * n2 + k2] = cur;
-            cur = host::mul_mod(cur, step, mod);
-        }
-    }
-    HIP_TRY(hipSetDevice(ctx->device));
-    HIP_TRY(p->tw.upload(tw));
-    HIP_TRY(p->buf0.alloc(N * sizeof(u64)));
-    HIP_TRY(p->buf1.alloc(N * sizeof(u64)));
     *out = p.release();
     return FHE_OK;
 }
@@ -481,36 +506,38 @@ int fhe_fourstep_destroy(fhe_fourstep *p)
 {
     if (p) {
         (void)hipSetDevice(p->ctx->device);
-        fhe_ntt_tables_destroy(p->t1);
-        fhe_ntt_tables_destroy(p->t2);
         delete p;
     }
     return FHE_OK;
 }
 
-int fhe_fourstep_ntt(fhe_ctx *ctx, uint64_t *d_dst, const uint64_t *d_src, fhe_fourstep *p, void *stream)
+int fhe_fourstep_ntt_batch(fhe_ctx *ctx, uint64_t *d_dst, const uint64_t *d_src, fhe_fourstep *p, size_t n_vec, void *stream)
 {
     if (!ctx || !d_dst || !d_src || !p) return fail(FHE_ERR_INVALID, "null argument");
+    if (!n_vec) return FHE_OK;
+    if (n_vec > ((size_t)1 << 24)) return fail(FHE_ERR_INVALID, "batch too large for one launch (max 2^24 vectors)");
     HIP_TRY(hipSetDevice(ctx->device));
     hipStream_t st = pick(ctx, stream);
-    u64 *b0 = p->buf0.as<u64>(), *b1 = p->buf1.as<u64>();
-    const u32 n1 = (u32)p->n1, n2 = (u32)p->n2;
-    hipError_t e;
-    // A[t2][t1] = a[t1 + n1 t2] (:81) -> b0[t1][t2]
-    if ((e = launch_transpose(st, b0, d_src, n2, n1)) != hipSuccess) return hip_fail(e, "transpose");
-    // step 1 (:84-90): n1 transforms of length n2 along t2; output bit-reversed in k2
-    PassArgs a1{b0, p->t2->d_lp.as<LimbParams>(), 0u, 1u, n1, 1u};
-    if ((e = launch_ntt(st, a1, p->log2, false, p->t2->path[0])) != hipSuccess) return hip_fail(e, "four-step column transforms");
-    // step 2 (:93) fused with the reordering: b1[k2][t1] = b0[t1][bitrev(k2)] * w^(k2 t1)
-    if ((e = launch_fourstep_mid(st, b1, b0, n1, n2, p->log2, p->tw.as<u64>(), p->mc, true)) != hipSuccess)
-        return hip_fail(e, "four-step twiddle");
-    // step 3 (:96-102): n2 transforms of length n1 along t1
-    PassArgs a2{b1, p->t1->d_lp.as<LimbParams>(), 0u, 1u, n2, 1u};
-    if ((e = launch_ntt(st, a2, p->log1, false, p->t1->path[0])) != hipSuccess) return hip_fail(e, "four-step row transforms");
-    // step 4 (:105-108): y[k1*n2 + k2] = Y[k1][k2] = b1[k2][bitrev(k1)]
-    if ((e = launch_fourstep_mid(st, d_dst, b1, n2, n1, p->log1, nullptr, p->mc, false)) != hipSuccess)
-        return hip_fail(e, "four-step output reorder");
+    const size_t words = n_vec << p->log_n;
+    if (p->tmp.bytes < words * 8) {
+        HIP_TRY(hipStreamSynchronize(st));      // growing frees the old block
+        HIP_TRY(p->tmp.alloc(words * 8));
+    }
+    if (!p->t) {
+        // N < 32: the small cyclic path works in place with a scratch buffer
+        if (d_dst != d_src) HIP_TRY(hipMemcpyAsync(d_dst, d_src, words * 8, hipMemcpyDeviceToDevice, st));
+        return fhe_ntt_cyclic(ctx, d_dst, p->tmp.as<u64>(), p->log_n, n_vec, p->mod, p->g, 0, 0, st);
+    }
+    PassArgs a{d_dst, p->t->d_lp.as<LimbParams>(), 0u, 1u, (u32)n_vec, 1u};
+    a.src = d_src;
+    hipError_t e = launch_ntt_gs(st, a, p->tmp.as<u64>(), p->log_n, p->t->path[0]);
+    if (e != hipSuccess) return hip_fail(e, "launch_ntt_gs");
     return FHE_OK;
+}
+
+int fhe_fourstep_ntt(fhe_ctx *ctx, uint64_t *d_dst, const uint64_t *d_src, fhe_fourstep *p, void *stream)
+{
+    return fhe_fourstep_ntt_batch(ctx, d_dst, d_src, p, 1, stream);
 }
 
 // ---------------------------------------------------------------- pointwise

@@ -111,8 +111,8 @@ struct fhe_ctx {
     int ks_fused = -1;     // key-switch inner product fused with the extended limbs' row pass: -1 = by shape, 0 = never, 1 = always (where supported)
     int only_pass = -1;    // measurement hook: 0 / 1 = launch only the first / second pass of a two-pass size
     int fused_variant = 7;   // handoff*2 + stream hint (ntt_launch.hpp); 7 = acquire + nt streaming
-    // cyclic tables keyed by (log_n, mod, root, convention)
-    std::map<std::tuple<int, u64, u64, int>, std::unique_ptr<fhe_ntt_tables>> cyclic;
+    // cyclic tables keyed by (log_n, mod, root, convention * 2 + natural-order form, scale folded into the last stage)
+    std::map<std::tuple<int, u64, u64, int, u64>, std::unique_ptr<fhe_ntt_tables>> cyclic;
     std::map<std::vector<u64>, std::unique_ptr<GarnerTables>> garner;
 };
 
@@ -175,11 +175,10 @@ struct fhe_keyswitch {
 
 struct fhe_fourstep {
     fhe_ctx *ctx = nullptr;
-    u64 n1 = 0, n2 = 0, mod = 0;
-    int log1 = 0, log2 = 0;
-    fhe_ntt_tables *t1 = nullptr, *t2 = nullptr; // sub-transform tables of length n1 / n2
-    DevBuf tw, buf0, buf1;
-    ModConst mc{};
+    u64 n1 = 0, n2 = 0, mod = 0, g = 0;
+    int log_n = 0;
+    fhe_ntt_tables *t = nullptr;   // natural-order table set of length n1 * n2 (owned by the context's cache)
+    DevBuf tmp;                    // hand-off buffer between the two launches, grown to the largest batch seen
 };
 
 
@@ -291,7 +290,8 @@ int keyswitch_core(fhe_ctx *ctx, fhe_keyswitch *p, uint64_t *d_out0, uint64_t *d
                    const uint64_t *d_add0, const uint64_t *d_add1, void *stream);
 // defined in capi.cpp
 int build_tables(fhe_ctx *ctx, int log_n, const fhe::u64 *q, int count, const fhe::u64 *fwd_rows, bool want_inverse, int force_path,
-                 const fhe::u64 *psi_or_null, fhe_ntt_tables **out);
+                 const fhe::u64 *psi_or_null, fhe_ntt_tables **out, const fhe::u64 *gs_scale = nullptr);
+int cyclic_tables(fhe_ctx *ctx, int log_n, fhe::u64 mod, fhe::u64 root, int convention, fhe::u64 scale, fhe_ntt_tables **out);
 int ntt_batch(fhe_ctx *ctx, fhe::u64 *d, const fhe_ntt_tables *t, size_t n_poly, size_t limbs, size_t start_idx, void *stream, bool inverse);
 int pointwise(fhe_ctx *ctx, fhe::u64 *c, const fhe::u64 *a, const fhe::u64 *b, const fhe_ntt_tables *t, size_t n_poly, size_t limbs,
               size_t start_idx, void *stream, bool acc);

@@ -25,6 +25,19 @@
 
 namespace fhe {
 
+// the low `bits` bits of v reversed (bits <= 32)
+FHE_HD u32 brev_bits(u32 v, int bits)
+{
+    if (bits <= 0) return 0;
+#if defined(__clang__)
+    return __builtin_bitreverse32(v) >> (32 - bits);
+#else
+    u32 r = 0;
+    for (int b = 0; b < bits; b++) r |= ((v >> b) & 1u) << (bits - 1 - b);
+    return r;
+#endif
+}
+
 FHE_HD constexpr int cmax(int a, int b) { return a > b ? a : b; }
 FHE_HD constexpr int cmin(int a, int b) { return a < b ? a : b; }
 
@@ -221,9 +234,10 @@ struct ColPass {
 
     // `base` points at the first element of this tile's column 0, point 0.
     // Phase index E counts in execution order (for the inverse the field order is reversed).
+    // `src` (optional): the loading step reads the tile from there (same offsets) instead of `base` -- out-of-place first launch.
     template <int E, class TAP = NoTap>
     static FHE_D void phase(int tid, u64 *__restrict__ base, elem *__restrict__ lds, TwPtr tw, u32 hi_prefix,
-                            const typename A::Ctx &c, const Tw &inv_n, TAP *tap = nullptr)
+                            const typename A::Ctx &c, const Tw &inv_n, TAP *tap = nullptr, const u64 *src = nullptr)
     {
         constexpr int F = INVERSE ? ST::NSTEP - 1 - E : E;   // which field (forward numbering) this step handles
         constexpr int K = ST::k(F);
@@ -244,10 +258,11 @@ struct ColPass {
             elem x[R];
             if (FIRST) {
                 u64 raw[R];
+                const u64 *ldb = src ? src : base;
 #pragma unroll
                 for (int r = 0; r < R; r++) {
-                    const u64 *src = base + (size_t)(g0 + ((u32)r << LOGS)) * STRIDE + col;
-                    raw[r] = COHERENT_IN == 1 ? load_coherent_u64(src) : (COHERENT_IN == 2 || (STREAM && IN_MODE == IO_CANONICAL)) ? load_stream_u64(src) : *src;
+                    const u64 *from = ldb + (size_t)(g0 + ((u32)r << LOGS)) * STRIDE + col;
+                    raw[r] = COHERENT_IN == 1 ? load_coherent_u64(from) : (COHERENT_IN == 2 || (STREAM && IN_MODE == IO_CANONICAL)) ? load_stream_u64(from) : *from;
                 }
                 convert_in<A, R, IN_MODE>(x, raw, c);
                 if constexpr (TAP::ACTIVE) {
@@ -331,8 +346,13 @@ FHE_HD constexpr u32 row_pad(u32 g) { return g + ((g >> 4) << 1); }
 
 // STAGE_BOTH: also stage the side that is not stride-1 (forward: the input) through a coalesced copy phase (tried for
 // the LDS-resident single pass: no gain, see ntt_plan.hpp; kept as a switch).
+// ROWMODE 1 (first launch of the natural-order transforms, INVERSE network only): the tile's TR rows are the network rows
+// r_i = bitrev(row0 + i) and its input comes from a NATURAL-order source -- network position (r, k) holds
+// src[bitrev(k) * 2^S0 + bitrev(r)], so the tile reads TR adjacent columns of the source seen as 2^P rows of 2^S0 words
+// (whole 8*TR-byte segments) and the bit reversal happens on the way into LDS.  That is the four-step's "column
+// transforms" batch reading its columns (reliability_test/four_step_ntt_prot.py:81-90) with no separate transpose.
 template <class A, class ST, int LOGN, int TR, int NTHREADS, bool INVERSE, int IN_MODE, int OUT_MODE, u32 RED,
-          int SBLK, int COHERENT_IN = 0, bool STREAM = false, bool STAGE_BOTH = false>
+          int SBLK, int COHERENT_IN = 0, bool STREAM = false, bool STAGE_BOTH = false, int ROWMODE = 0>
 struct RowPass {
     typedef A Arith;
     typedef typename A::elem elem;
@@ -348,6 +368,24 @@ struct RowPass {
     static constexpr bool STAGE_IN = STAGED && (INVERSE || STAGE_BOTH), STAGE_OUT = STAGED && (!INVERSE || STAGE_BOTH);
     static constexpr int NPHASE = ST::NSTEP + (STAGE_IN ? 1 : 0) + (STAGE_OUT ? 1 : 0);
     static constexpr int TILES = (1 << S0) / TR;
+    static_assert(ROWMODE == 0 || (INVERSE && NPTS >= 32), "the gathering first launch belongs to the inverse-structured network");
+
+    // network row of the tile's local row
+    static FHE_HD u32 net_row(u32 row0, u32 row)
+    {
+        if (ROWMODE == 0) return row0 + row;
+        return brev_bits(row0 + row, S0);
+    }
+    // ROWMODE 1: natural-order source (limb base) -> LDS image, bit reversal folded in
+    static FHE_D void gather_in(int tid, const u64 *__restrict__ src, u32 row0, elem *__restrict__ lds)
+    {
+        for (int i = tid; i < TR * NPTS; i += NTHREADS) {
+            const u32 ki = (u32)i % TR, rho = (u32)i / TR;
+            const u32 k = brev_bits(rho, P);
+            const u64 v = src[((size_t)rho << S0) + row0 + ki];
+            lds[ki * ROW_LDS + row_pad(k)] = __builtin_bit_cast(elem, v);
+        }
+    }
 
     // coalesced copy HBM -> LDS (inverse, raw words): 2 points (16 bytes) per lane
     static FHE_D void copy_in(int tid, const u64 *__restrict__ base, elem *__restrict__ lds)
@@ -395,13 +433,16 @@ struct RowPass {
         }
     }
 
-    // `base` = first element of the tile's first row; `row0` = index of that row in the limb.
+    // `base` = first element of the tile's first row; `row0` = index of that row in the limb.  (ROWMODE 1: `base` = the
+    // LIMB's first element -- the tile's rows are not adjacent -- and `src` = the natural-order source limb.)
+    // `src` (optional, ROWMODE 0): the loading step reads the tile from there instead of `base` -- out-of-place first launch.
     template <int E, class TAP = NoTap>
     static FHE_D void phase(int tid, u64 *__restrict__ base, elem *__restrict__ lds, TwPtr tw, u32 row0,
-                            const typename A::Ctx &c, const Tw &inv_n, TAP *tap = nullptr)
+                            const typename A::Ctx &c, const Tw &inv_n, TAP *tap = nullptr, const u64 *src = nullptr)
     {
         if constexpr (STAGE_IN && E == 0) {
-            copy_in(tid, base, lds);
+            if constexpr (ROWMODE == 1) gather_in(tid, src, row0, lds);
+            else copy_in(tid, src ? src : base, lds);
         } else if constexpr (STAGE_OUT && E == NPHASE - 1) {
             copy_out<TAP>(tid, base, lds, c, tap);
         } else {
@@ -423,7 +464,7 @@ struct RowPass {
                 const u32 row = (u32)u / NSETS, su = (u32)u % NSETS;
                 const u32 a = su >> LOGS, cc = su & (S - 1);
                 const u32 g0 = ((a << K) << LOGS) + cc;
-                u64 *__restrict__ grow = base + (size_t)row * NPTS;
+                u64 *__restrict__ grow = base + (size_t)(ROWMODE == 1 ? net_row(row0, row) : row) * NPTS;
                 elem *__restrict__ lrow = lds + row * ROW_LDS;
                 elem x[R];
                 if (FIRST) {
@@ -431,8 +472,8 @@ struct RowPass {
 #pragma unroll
                     for (int r = 0; r < R; r++) {
                         if (FROM_GLOBAL) {
-                            const u64 *src = grow + g0 + ((u32)r << LOGS);
-                            raw[r] = COHERENT_IN == 1 ? load_coherent_u64(src) : (COHERENT_IN == 2 || (STREAM && IN_MODE == IO_CANONICAL)) ? load_stream_u64(src) : *src;
+                            const u64 *from = (src ? src + (size_t)row * NPTS : grow) + g0 + ((u32)r << LOGS);
+                            raw[r] = COHERENT_IN == 1 ? load_coherent_u64(from) : (COHERENT_IN == 2 || (STREAM && IN_MODE == IO_CANONICAL)) ? load_stream_u64(from) : *from;
                         } else {
                             raw[r] = __builtin_bit_cast(u64, lrow[row_pad(g0 + ((u32)r << LOGS))]);
                         }
@@ -446,7 +487,7 @@ struct RowPass {
 #pragma unroll
                     for (int r = 0; r < R; r++) x[r] = lrow[row_pad(g0 + ((u32)r << LOGS))];
                 }
-                const u32 prefix = ((row0 + row) << DONE) | a;
+                const u32 prefix = (net_row(row0, row) << DONE) | a;
                 constexpr bool FOLD = INVERSE && LAST && OUT_MODE == IO_CANONICAL && S0 + DONE == 0;
                 if (INVERSE) radix_inv<A, K, RED, U0, SBLK, FOLD>(x, tw, S0 + DONE, prefix, c, &inv_n);
                 else radix_fwd<A, K, RED, U0, SBLK>(x, tw, S0 + DONE, prefix, c);

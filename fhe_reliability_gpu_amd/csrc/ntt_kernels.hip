@@ -24,11 +24,43 @@ __global__ __launch_bounds__(NTT_THREADS) void k_ntt_pass(PassArgs a)
     const TwPtr tw = as_global(INV ? p.inv : p.fwd);
     const Tw inv_n = p.inv_n;
     const int tid = threadIdx.x;
-    PASS::template phase<0>(tid, base, lds, tw, row0, ctx, inv_n);
+    const u64 *from = a.src ? a.src + (base - a.data) : nullptr;      // out-of-place: this launch loads from the source buffer
+    PASS::template phase<0>(tid, base, lds, tw, row0, ctx, inv_n, (NoTap *)nullptr, from);
     if constexpr (PASS::NPHASE > 1) {
         __syncthreads();
         PASS::template phase<1>(tid, base, lds, tw, row0, ctx, inv_n);
     }
+    if constexpr (PASS::NPHASE > 2) {
+        __syncthreads();
+        PASS::template phase<2>(tid, base, lds, tw, row0, ctx, inv_n);
+    }
+    if constexpr (PASS::NPHASE > 3) {
+        __syncthreads();
+        PASS::template phase<3>(tid, base, lds, tw, row0, ctx, inv_n);
+    }
+}
+
+// First launch of the natural-order (cyclic / four-step) transforms: the inverse-structured row pass on network rows
+// bitrev(row0 + i), fed from the natural-order source a.src (ntt_core.hpp RowPass ROWMODE 1), results to a.data.
+template <class PASS, int LOGN>
+__global__ __launch_bounds__(NTT_THREADS) void k_ntt_gs_first(PassArgs a)
+{
+    typedef typename PASS::Arith A;
+    __shared__ __attribute__((aligned(16))) typename PASS::elem lds[PASS::LDS_ELEMS];
+    const u32 unit = blockIdx.x / PASS::TILES, tile = blockIdx.x % PASS::TILES;
+    const u32 polys = a.units / a.limbs, l = unit / polys, poly = unit % polys;
+    const size_t off = ((size_t)poly * a.poly_stride + l) << LOGN;
+    const LimbParams &p = a.lp[a.limb0 + l];
+    const typename A::Ctx ctx = A::make_ctx(p);
+    const TwPtr tw = as_global(p.inv);
+    const Tw inv_n = p.inv_n;
+    const int tid = threadIdx.x;
+    const u32 row0 = tile * PASS::TROWS;
+    u64 *base = a.data + off;
+    const u64 *from = a.src + off;
+    PASS::template phase<0>(tid, base, lds, tw, row0, ctx, inv_n, (NoTap *)nullptr, from);
+    __syncthreads();
+    PASS::template phase<1>(tid, base, lds, tw, row0, ctx, inv_n);
     if constexpr (PASS::NPHASE > 2) {
         __syncthreads();
         PASS::template phase<2>(tid, base, lds, tw, row0, ctx, inv_n);
@@ -168,17 +200,60 @@ static hipError_t launch_transform(hipStream_t st, const PassArgs &a, int which,
             return hipGetLastError();
         }
     }
+    PassArgs second = a;            // only the first launch of a transform reads from a.src
+    second.src = nullptr;
     if constexpr (!PS::G::TWO_PASS) {
         if (which == 1) return hipSuccess;
         return launch_pass<typename PS::Single, LOGN, INV, false>(st, a);
     } else if constexpr (!INV) {
         hipError_t e = which == 1 ? hipSuccess : launch_pass<typename PS::Col, LOGN, INV, true>(st, a);
         if (e != hipSuccess || which == 0) return e;
-        return launch_pass<typename PS::Row, LOGN, INV, false>(st, a);
+        return launch_pass<typename PS::Row, LOGN, INV, false>(st, second);
     } else {
         hipError_t e = which == 1 ? hipSuccess : launch_pass<typename PS::Row, LOGN, INV, false>(st, a);
         if (e != hipSuccess || which == 0) return e;
-        return launch_pass<typename PS::Col, LOGN, INV, true>(st, a);
+        return launch_pass<typename PS::Col, LOGN, INV, true>(st, second);
+    }
+}
+
+// Natural-order transform (motivation/ntt.py:8-32; the four-step flow of reliability_test/four_step_ntt_prot.py:71-109):
+// the inverse-structured network with a cyclic table in the inverse slot maps bit-reversed input to natural output, and the
+// bit reversal is folded into the first launch's loads.  a.src = natural-order input, a.data = natural-order output,
+// tmp = hand-off buffer of the same layout (two-launch sizes; a.src may equal a.data).
+template <class A, int LOGN>
+static hipError_t launch_gs_t(hipStream_t st, const PassArgs &a, u64 *tmp)
+{
+    constexpr int GEO = LOGN >= 13 ? 1 : 0;
+    typedef Passes<A, LOGN, true, GEO> PS;
+    constexpr bool TWO = PS::G::TWO_PASS;
+    typedef RowPass<A, typename PS::PL::Row, LOGN, TWO ? PS::G::TR : 1, NTT_THREADS, true, IO_CANONICAL, TWO ? IO_LAZY : IO_CANONICAL, PS::RED_FIRST,
+                    PS::SB, 0, false, false, 1> First;
+    if constexpr (!TWO) {
+        hipLaunchKernelGGL((k_ntt_gs_first<First, LOGN>), dim3(a.units * First::TILES), dim3(NTT_THREADS), 0, st, a);
+        return hipGetLastError();
+    } else {
+        if (!tmp) return hipErrorInvalidValue;
+        PassArgs first = a, second = a;
+        first.data = tmp;
+        second.src = tmp;
+        hipLaunchKernelGGL((k_ntt_gs_first<First, LOGN>), dim3(a.units * First::TILES), dim3(NTT_THREADS), 0, st, first);
+        return launch_pass<typename PS::Col, LOGN, true, true>(st, second);
+    }
+}
+
+bool ntt_gs_supported(int logn) { return logn >= 5 && logn <= NTT_MAX_LOGN; }
+
+hipError_t launch_ntt_gs(hipStream_t st, const PassArgs &a, u64 *tmp, int logn, int path)
+{
+    if (a.units == 0) return hipSuccess;
+    if (!a.src || a.map || !ntt_gs_supported(logn)) return hipErrorInvalidValue;
+    switch (logn) {
+#define FHE_CASE(L) \
+    case L: return path == PATH_F64 ? launch_gs_t<ArithF64, L>(st, a, tmp) : launch_gs_t<ArithU64, L>(st, a, tmp);
+        FHE_CASE(5) FHE_CASE(6) FHE_CASE(7) FHE_CASE(8) FHE_CASE(9) FHE_CASE(10) FHE_CASE(11) FHE_CASE(12) FHE_CASE(13)
+        FHE_CASE(14) FHE_CASE(15) FHE_CASE(16) FHE_CASE(17) FHE_CASE(18) FHE_CASE(19) FHE_CASE(20)
+#undef FHE_CASE
+    default: return hipErrorInvalidValue;
     }
 }
 
@@ -788,6 +863,11 @@ size_t ntt_packed_scratch_words() { return (size_t)256 * PK_BLOCK_WORDS; }
 hipError_t launch_ntt(hipStream_t st, const PassArgs &a, int logn, bool inverse, int path, int geo, int which, bool resident)
 {
     if (a.units == 0) return hipSuccess;
+    if (a.src) {               // out-of-place: the plain launches only (no packed hand-off, no resident pass)
+        if (a.scratch) return hipErrorInvalidValue;
+        geo = 1;
+        resident = false;
+    }
     return path == PATH_F64 ? launch_size<ArithF64>(st, a, logn, inverse, geo, which, resident)
                             : launch_size<ArithU64>(st, a, logn, inverse, geo, which, resident);
 }

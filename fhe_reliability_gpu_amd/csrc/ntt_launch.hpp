@@ -12,6 +12,12 @@ namespace fhe {
 // resident (opt-in): sizes whose limb fits a CU's LDS (2^13, 2^14) run as ONE LDS-resident pass when the whole transform is asked for
 hipError_t launch_ntt(hipStream_t st, const PassArgs &a, int logn, bool inverse, int path, int geo = 1, int which = -1, bool resident = false);
 
+// Natural-order transform (cyclic NTT of motivation/ntt.py:8-32 / the four-step flow): a.src = natural-order input,
+// a.data = natural-order output (may alias), tmp = hand-off buffer of the same layout for the two-launch sizes.  The limbs'
+// INVERSE table slot must hold the cyclic table (capi.cpp build_tables, GS mode).  2^5 .. 2^20.
+bool ntt_gs_supported(int logn);
+hipError_t launch_ntt_gs(hipStream_t st, const PassArgs &a, u64 *tmp, int logn, int path);
+
 // c = a * b mod (x^N + 1, q_l): forward column passes, one launch that finishes both forward transforms,
 // multiplies and starts the inverse, inverse column pass.  a and b are scratch afterwards.
 bool polymul_fused_supported(int logn);
@@ -97,10 +103,6 @@ struct ModConst {
 // per unit of 2^logn words: dst[i] = src[bitrev(i)] (* scale mod q when do_scale).  dst != src.
 hipError_t launch_bitrev_scale(hipStream_t st, u64 *dst, const u64 *src, int logn, u32 units, const ModConst &mc, u64 scale,
                                bool do_scale);
-// out[c][r] = in[r][bitrev(c)] (* tw[r*cols + c])   (four-step twiddle + transpose)
-hipError_t launch_fourstep_mid(hipStream_t st, u64 *out, const u64 *in, u32 rows, u32 cols, int log_cols,
-                               const u64 *tw, const ModConst &mc, bool with_twiddle);
-hipError_t launch_transpose(hipStream_t st, u64 *out, const u64 *in, u32 rows, u32 cols);
 // out_h = (a_h - b_h) * scal[l] (+ add_h) mod q_l over `limbs` limbs from table index limb0, for one half
 // (out1 == nullptr) or both halves of a key switch in one launch; a_h = a + h * a_stride, b_h = b + h * b_stride (in words)
 struct SubScaleArgs {

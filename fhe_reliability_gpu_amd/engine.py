@@ -294,11 +294,25 @@ def poly_mul_negacyclic_ntt(a, b, psi: int, mod: int, eng: Optional[Engine] = No
     return [int(x) for x in da.download()]
 
 
-def four_step_ntt(a, N: int, mod: int = 998244353, g: int = 3, n1: Optional[int] = None, eng: Optional[Engine] = None) -> List[int]:
+def four_step_ntt(a, N: int, mod: int = 998244353, g: int = 3, n1: Optional[int] = None, eng: Optional[Engine] = None):
     """``four_step_ntt(a, N, mod, g)`` of reliability_test/four_step_ntt_prot.py:71-109.
-    ``n1`` defaults to sqrt(N) as in the reference (:73-75); any power-of-two split is accepted."""
+    ``n1`` defaults to sqrt(N) as in the reference (:73-75); any power-of-two split is accepted.  ``a`` may be a batch
+    ([n_vec][N]): one call transforms all vectors (two launches in total) and a list of lists comes back."""
     eng = eng or default_engine()
     log_n = _log2(N)
+    arr = _arr(a)
+    if arr.ndim == 2:
+        if n1 is None:
+            n1 = 1 << (log_n // 2)
+        h = vp()
+        check(lib.fhe_fourstep_create(eng._h, n1, N // n1, mod, g, C.byref(h)))
+        try:
+            src = eng.upload(arr)
+            dst = eng.alloc(arr.size)
+            check(lib.fhe_fourstep_ntt_batch(eng._h, dst.ptr, src.ptr, h, arr.shape[0], None))
+            return dst.download().reshape(arr.shape).tolist()
+        finally:
+            lib.fhe_fourstep_destroy(h)
     if n1 is None:
         n1 = 1 << (log_n // 2)
         if n1 * n1 != N:

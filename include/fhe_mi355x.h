@@ -141,11 +141,15 @@ int fhe_ntt_cyclic(fhe_ctx *ctx, uint64_t *d_data, uint64_t *d_scratch, int log_
 
 /* ---- four-step transform (a6) -------------------------------------------------- */
 /* four_step_ntt(a, N) of reliability_test/four_step_ntt_prot.py:71-109 with N = n1*n2
- * (both powers of two, n1 != n2 allowed): column transforms, twiddle w^(k2 t1), row
+ * (both powers of two, n1 != n2 allowed, N <= 2^20): column transforms, twiddle w^(k2 t1), row
  * transforms, transposed output; equals ntt_direct (:49-58).  g = generator (G=3, :17). */
 int fhe_fourstep_create(fhe_ctx *ctx, uint64_t n1, uint64_t n2, uint64_t mod, uint64_t g, fhe_fourstep **out);
 int fhe_fourstep_destroy(fhe_fourstep *p);
 int fhe_fourstep_ntt(fhe_ctx *ctx, uint64_t *d_dst, const uint64_t *d_src, fhe_fourstep *p, void *stream);
+/* n_vec vectors of n1*n2 words each, contiguous; d_dst may equal d_src.  Two launches for the whole batch: the column
+ * transforms read the input's columns directly (no transpose pass), the row transforms carry the twiddle step in their
+ * butterflies and write natural order. */
+int fhe_fourstep_ntt_batch(fhe_ctx *ctx, uint64_t *d_dst, const uint64_t *d_src, fhe_fourstep *p, size_t n_vec, void *stream);
 
 /* ---- coefficient-wise products (a4, a5) ------------------------------------------ */
 /* C_hat[i] = A_hat[i] * B_hat[i] % mod (rfhe_framewk/src/negaclic_ntt.py:126), per limb;

@@ -690,3 +690,46 @@ def test_packed_handoff_equals_plain(F, eng, O):
     assert (out[0] == out[1]).all()
     for p, l in ((0, 0), (4, 2), (2, 1)):
         assert (out[1][p, l] == O.nwt_forward(data[p, l] % np.uint64(qs[l]), qs[l], O.root_powers(qs[l], logn))).all()
+
+
+# ------------------------------------------------------------------ natural-order transforms as first-class launches
+@pytest.mark.parametrize("n1,n2", [(512, 256), (256, 512), (256, 256), (64, 128), (4, 8), (2, 2)])
+def test_four_step_unequal_factors_match_reference_flow(F, O, n1, n2):
+    """four_step_ntt with n1 != n2 (BASELINE config 4's 2^17 = 512 x 256 among them) against the oracle's restatement of the
+    reference's four-step flow (reliability_test/four_step_ntt_prot.py:71-109, generalised to n1 != n2) -- which itself equals
+    ntt_direct."""
+    mod, g = 998244353, 3
+    N = n1 * n2
+    rng = np.random.default_rng(n1 + 3 * n2)
+    a = rng.integers(0, mod, N, dtype=np.uint64)
+    want = O.four_step_ntt(a, n1, n2, mod, g)
+    assert (np.array(F.four_step_ntt(a, N, mod, g, n1=n1), dtype=np.uint64) == want).all()
+
+
+@pytest.mark.parametrize("logn,n_vec", [(5, 3), (9, 4), (12, 5), (13, 5), (16, 3), (18, 2)])
+def test_four_step_batch_and_cyclic_round_trip(F, eng, O, logn, n_vec):
+    """A batch of vectors in one call (two launches in total), every size class of the natural-order transform; then
+    motivation/bsgs.py:31-36's intt brings the batch back (the scale n^-1 rides on the last stage)."""
+    import ctypes as C
+    from fhe_reliability_gpu_amd._lib import check, lib
+    mod, g = 998244353, 3
+    N = 1 << logn
+    rng = np.random.default_rng(logn)
+    a = rng.integers(0, mod, (n_vec, N), dtype=np.uint64)
+    a[0, :4] = [0, 1, mod - 1, 2**64 - 1]                       # an out-of-range word is reduced first
+    got = np.array(F.four_step_ntt(a, N, mod, g, n1=1 << (logn // 2)), dtype=np.uint64)
+    for v in range(n_vec):
+        assert (got[v] == O.ntt_cyclic(a[v] % np.uint64(mod), mod, g)).all()
+    d, s = eng.upload(got), eng.alloc(got.size)
+    check(lib.fhe_ntt_cyclic(eng._h, d.ptr, s.ptr, logn, n_vec, mod, g, 0, 1, None))
+    assert (d.download().reshape(n_vec, N) == a % np.uint64(mod)).all()
+
+
+def test_cyclic_61_bit_and_composite_modulus_large(F, O):
+    """the integer path and a composite modulus (motivation/ntt.py:36's 15728641 = 173 x 90917) through the natural-order launches"""
+    rng = np.random.default_rng(61)
+    a = rng.integers(0, Q61, 1 << 14, dtype=np.uint64)
+    assert F.ntt([int(x) for x in a], Q61, 37) == [int(x) for x in O.ntt_cyclic(a, Q61, 37)]
+    mod = 15728641
+    b = rng.integers(0, mod, 1 << 13, dtype=np.uint64)
+    assert F.ntt([int(x) for x in b], mod, 3) == [int(x) for x in O.ntt_cyclic(b, mod, 3)]
