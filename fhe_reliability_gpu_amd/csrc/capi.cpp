@@ -75,10 +75,17 @@ int build_tables(fhe_ctx *ctx, int log_n, const u64 *q, int count, const u64 *fw
     return FHE_OK;
 }
 
+// d_src (optional): out-of-place -- the input is read from there (same layout), nothing is copied (PassArgs::src)
 int ntt_batch(fhe_ctx *ctx, u64 *d, const fhe_ntt_tables *t, size_t n_poly, size_t limbs, size_t start_idx, void *stream,
-              bool inverse)
+              bool inverse, const u64 *d_src)
 {
     if (!ctx || !d) return fail(FHE_ERR_INVALID, "null argument");
+    if (d_src && (ctx->mode == 1 || ctx->fault_idx >= 0 || ctx->packed_on || ctx->only_pass >= 0 || ctx->resident)) {
+        // the experimental variants and the test hooks work in place: copy first
+        HIP_TRY(hipSetDevice(ctx->device));
+        if (d_src != d) HIP_TRY(hipMemcpyAsync(d, d_src, (n_poly * limbs << t->log_n) * 8, hipMemcpyDeviceToDevice, pick(ctx, stream)));
+        d_src = nullptr;
+    }
     int rc = check_range(t, n_poly, limbs, start_idx);
     if (rc) return rc;
     if (inverse && !t->has_inverse) return fail(FHE_ERR_UNSUPPORTED, "table set has no inverse (twiddle or N not invertible)");
@@ -89,6 +96,7 @@ int ntt_batch(fhe_ctx *ctx, u64 *d, const fhe_ntt_tables *t, size_t n_poly, size
     TraceScope tr(ctx, st, "NTT");
     return for_each_run(t, limbs, start_idx, [&](size_t off, size_t len, int path) -> int {
         PassArgs a{d + off * N, t->d_lp.as<LimbParams>(), (u32)(start_idx + off), (u32)len, (u32)(n_poly * len), (u32)limbs};
+        if (d_src) a.src = d_src + off * N;
         hipError_t e;
         if (ctx->mode == 1 && fused_supported(t->log_n)) {
             DevBuf *ctl;
@@ -127,7 +135,24 @@ int ntt_batch(fhe_ctx *ctx, u64 *d, const fhe_ntt_tables *t, size_t n_poly, size
                 }
                 a.scratch = sc->as<u64>();
             }
-            e = launch_ntt(st, a, t->log_n, inverse, path, ctx->geo, ctx->only_pass, ctx->resident);
+            // Batches that cannot stay in the 256 MiB Infinity Cache between the two launches are cut into sub-batches that can:
+            // a sub-batch's second launch then finds the first one's output on-die (measured on 512 MiB / 2 GiB batches:
+            // 0.30 -> 0.32-0.35 of the roofline depending on how many streams run, profiles/r02_chunk_sweep.txt; "ntt_chunk_mib" tunes it).  Limb-major launch order keeps whole limbs together.
+            const size_t unit_bytes = N * 8, total = (size_t)a.units * unit_bytes, chunk_bytes = (size_t)ctx->chunk_mib << 20;
+            if (chunk_bytes && t->log_n >= 13 && ctx->only_pass < 0 && !a.scratch && total > chunk_bytes + (chunk_bytes >> 1) && n_poly > 1) {
+                const size_t per = std::max<size_t>(1, chunk_bytes / (unit_bytes * len));      // polynomials per sub-batch
+                e = hipSuccess;
+                for (size_t p0 = 0; p0 < n_poly && e == hipSuccess; p0 += per) {
+                    PassArgs c = a;
+                    const size_t cnt = std::min(per, n_poly - p0);
+                    c.data = a.data + p0 * limbs * N;
+                    if (a.src) c.src = a.src + p0 * limbs * N;
+                    c.units = (u32)(cnt * len);
+                    e = launch_ntt(st, c, t->log_n, inverse, path, ctx->geo, -1, false);
+                }
+            } else {
+                e = launch_ntt(st, a, t->log_n, inverse, path, ctx->geo, ctx->only_pass, ctx->resident);
+            }
         }
         if (e != hipSuccess) return hip_fail(e, "launch_ntt");
         return FHE_OK;
@@ -246,6 +271,7 @@ int fhe_ctx_set_option(fhe_ctx *ctx, const char *name, long value)
     else if (!std::strcmp(name, "tile_geo")) ctx->geo = value ? 1 : 0;
     else if (!std::strcmp(name, "ntt_resident")) ctx->resident = value != 0;
     else if (!std::strcmp(name, "ntt_packed")) ctx->packed_on = value != 0;
+    else if (!std::strcmp(name, "ntt_chunk_mib")) ctx->chunk_mib = (unsigned)std::max(0l, value);
     else if (!std::strcmp(name, "ks_fused")) ctx->ks_fused = value < 0 ? -1 : value ? 1 : 0;
     else if (!std::strcmp(name, "ntt_only_pass")) ctx->only_pass = value == 0 ? 0 : value == 1 ? 1 : -1;   // bench.py times each kernel with it
     else if (!std::strcmp(name, "fused_skip_teams")) ctx->fused_skip_teams = (unsigned)value;   // test hook

@@ -63,14 +63,26 @@ static int rescale_core(fhe_ctx *ctx, fhe_keyswitch *p, uint64_t *const *outs, c
     e = launch_baseconv_exact_jobs(st, p->rs_jobs.as<BcJob>(), (u32)n_parts, 1, (int)R, p->last->dev.f64 != 0, N);
     if (e != hipSuccess) return hip_fail(e, "launch_baseconv_exact_jobs");
     if (p->plain_modulus && (rc = fhe_scalar_affine(ctx, delta, delta, p->t_mod_Q.data(), nullptr, t, n_parts, R, 0, st))) return rc;
-    if ((rc = ntt_batch(ctx, delta, t, n_parts, R, 0, st, false))) return rc;
-    for (size_t part = 0; part < n_parts; part += 2) {
-        const bool two = part + 1 < n_parts;
-        const SubScaleArgs sa{outs[part], two ? outs[part + 1] : nullptr, d_in + part * L * N, delta + part * R * N, nullptr,
-                              p->qlast_inv.as<u64>(), (u64)(L * N), (u64)(R * N), lp, 0u, (u32)R, p->log_n, nullptr};
-        if ((e = launch_sub_scale(st, sa)) != hipSuccess) return hip_fail(e, "launch_sub_scale");
+    const bool plain = !ntt_subscale_supported(p->log_n) || ctx->mode != 0 || ctx->fault_idx >= 0 || ctx->packed_on || ctx->only_pass >= 0 || ctx->resident;
+    if (plain) {
+        if ((rc = ntt_batch(ctx, delta, t, n_parts, R, 0, st, false))) return rc;
+        for (size_t part = 0; part < n_parts; part += 2) {
+            const bool two = part + 1 < n_parts;
+            const SubScaleArgs sa{outs[part], two ? outs[part + 1] : nullptr, d_in + part * L * N, delta + part * R * N, nullptr,
+                                  p->qlast_inv.as<u64>(), (u64)(L * N), (u64)(R * N), lp, 0u, (u32)R, p->log_n, nullptr};
+            if ((e = launch_sub_scale(st, sa)) != hipSuccess) return hip_fail(e, "launch_sub_scale");
+        }
+        return FHE_OK;
     }
-    return FHE_OK;
+    // forward transform of the residues with (c - delta) / q_last riding on its last pass
+    TraceScope tr_ntt(ctx, st, "NTT");
+    return for_each_run(t, R, 0, [&](size_t off, size_t len, int path) -> int {
+        PassArgs a{delta + off * N, lp, (u32)off, (u32)len, (u32)(n_parts * len), (u32)R};
+        RowEpiArgs ep{{nullptr, nullptr, nullptr}, {nullptr, nullptr, nullptr}, d_in + off * N, (u64)(L * N), p->qlast_inv.as<u64>() + off};
+        for (size_t i = 0; i < n_parts; i++) ep.out[i] = outs[i] + off * N;
+        hipError_t e2 = launch_ntt_subscale(st, a, ep, p->log_n, path);
+        return e2 == hipSuccess ? FHE_OK : hip_fail(e2, "launch_ntt_subscale");
+    });
 }
 
 extern "C" {

@@ -108,6 +108,7 @@ struct fhe_ctx {
     u32 pfault_block = 0, pfault_word = 0;      // (fhe_ctx_inject_fault_in_pass): workgroup and LDS word
     int geo = 1;           // column-tile geometry of the two-launch path (ntt_launch.hpp)
     bool resident = false; // 2^13 / 2^14: one LDS-resident pass instead of two launches (opt-in, see ntt_plan.hpp)
+    unsigned chunk_mib = 128; // two-launch transforms of larger batches run as sub-batches of this size (0 = off), capi.cpp ntt_batch
     int ks_fused = -1;     // key-switch inner product fused with the extended limbs' row pass: -1 = by shape, 0 = never, 1 = always (where supported)
     int only_pass = -1;    // measurement hook: 0 / 1 = launch only the first / second pass of a two-pass size
     int fused_variant = 7;   // handoff*2 + stream hint (ntt_launch.hpp); 7 = acquire + nt streaming
@@ -292,7 +293,8 @@ int keyswitch_core(fhe_ctx *ctx, fhe_keyswitch *p, uint64_t *d_out0, uint64_t *d
 int build_tables(fhe_ctx *ctx, int log_n, const fhe::u64 *q, int count, const fhe::u64 *fwd_rows, bool want_inverse, int force_path,
                  const fhe::u64 *psi_or_null, fhe_ntt_tables **out, const fhe::u64 *gs_scale = nullptr);
 int cyclic_tables(fhe_ctx *ctx, int log_n, fhe::u64 mod, fhe::u64 root, int convention, fhe::u64 scale, fhe_ntt_tables **out);
-int ntt_batch(fhe_ctx *ctx, fhe::u64 *d, const fhe_ntt_tables *t, size_t n_poly, size_t limbs, size_t start_idx, void *stream, bool inverse);
+int ntt_batch(fhe_ctx *ctx, fhe::u64 *d, const fhe_ntt_tables *t, size_t n_poly, size_t limbs, size_t start_idx, void *stream, bool inverse,
+              const fhe::u64 *d_src = nullptr);
 int pointwise(fhe_ctx *ctx, fhe::u64 *c, const fhe::u64 *a, const fhe::u64 *b, const fhe_ntt_tables *t, size_t n_poly, size_t limbs,
               size_t start_idx, void *stream, bool acc);
 

@@ -192,8 +192,7 @@ static int ks_begin(fhe_ctx *ctx, fhe_keyswitch *p, const uint64_t *d_c, hipStre
     if (!sh.cn) return FHE_OK;
     const size_t N = (size_t)1 << p->log_n;
     u64 *slot = p->g1 + (size_t)sh.rank * sh.cmax * N;
-    HIP_TRY(hipMemcpyAsync(slot, d_c, (size_t)sh.cn * N * 8, hipMemcpyDeviceToDevice, st));
-    return ntt_batch(ctx, slot, p->t, 1, sh.cn, sh.clo, st, true);
+    return ntt_batch(ctx, slot, p->t, 1, sh.cn, sh.clo, st, true, d_c);     // out of place: the input is the caller's, no copy
 }
 
 // base extension of each digit to every other owned prime (MODREDUCTION, 16384_4:471-452), their transforms, and the inner
@@ -288,10 +287,23 @@ static int ks_finish(fhe_ctx *ctx, fhe_keyswitch *p, uint64_t *d_out0, uint64_t 
     hipError_t e = launch_baseconv_exact_jobs(st, p->down_jobs.as<BcJob>(), 2, p->down->dev.m, p->down->dev.k, p->down->dev.f64 != 0, N);
     if (e != hipSuccess) return hip_fail(e, "launch_baseconv_exact_jobs");
     if (p->plain_modulus && (rc = fhe_scalar_affine(ctx, conv, conv, p->t_mod_Q.data() + sh.clo, nullptr, t, 2, sh.cn, sh.clo, st))) return rc;
-    if ((rc = ntt_batch(ctx, conv, t, 2, sh.cn, sh.clo, st, false))) return rc;
-    const SubScaleArgs sa{d_out0, d_out1, acc, conv, d_add0, p->pinv.as<u64>(), (u64)(MO * N), (u64)((size_t)sh.cn * N), lp, (u32)sh.clo, (u32)sh.cn, p->log_n, d_add1};
-    if ((e = launch_sub_scale(st, sa)) != hipSuccess) return hip_fail(e, "launch_sub_scale");
-    return FHE_OK;
+    const bool plain = !ntt_subscale_supported(p->log_n) || ctx->mode != 0 || ctx->fault_idx >= 0 || ctx->packed_on || ctx->only_pass >= 0 || ctx->resident;
+    if (plain) {
+        if ((rc = ntt_batch(ctx, conv, t, 2, sh.cn, sh.clo, st, false))) return rc;
+        const SubScaleArgs sa{d_out0, d_out1, acc, conv, d_add0, p->pinv.as<u64>(), (u64)(MO * N), (u64)((size_t)sh.cn * N), lp, (u32)sh.clo, (u32)sh.cn, p->log_n, d_add1};
+        if ((e = launch_sub_scale(st, sa)) != hipSuccess) return hip_fail(e, "launch_sub_scale");
+        return FHE_OK;
+    }
+    // the converted limbs' forward transform with the tail -- subtract from acc, times P^-1, plus the optional addends -- riding on
+    // its last pass: neither the transformed limbs nor a separate tail launch exist
+    TraceScope tr_ntt(ctx, st, "NTT");
+    return for_each_run(t, sh.cn, sh.clo, [&](size_t off, size_t len, int path) -> int {
+        PassArgs a{conv + off * N, lp, (u32)(sh.clo + off), (u32)len, (u32)(2 * len), (u32)sh.cn};
+        const RowEpiArgs ep{{d_out0 + off * N, d_out1 + off * N, nullptr}, {d_add0 ? d_add0 + off * N : nullptr, d_add1 ? d_add1 + off * N : nullptr, nullptr},
+                            acc + off * N, (u64)(MO * N), p->pinv.as<u64>() + off};
+        hipError_t e2 = launch_ntt_subscale(st, a, ep, p->log_n, path);
+        return e2 == hipSuccess ? FHE_OK : hip_fail(e2, "launch_ntt_subscale");
+    });
 }
 
 // Hybrid RNS key switching on one device, operation order of the reference's SEAL trace (profile_framewk/build/data/ckks/16384_4:466-539)

@@ -203,6 +203,7 @@ template <class P> FHE_HD u64 pk_extract(P w, u32 idx)
 struct NoTap {
     static constexpr bool ACTIVE = false;
     static constexpr bool MID = false;    // MID: the tap also sees the lazy words a column pass hands to the next launch
+    static constexpr bool STORES = false; // STORES: the tap writes the forward row pass's results itself (an epilogue fused into the pass)
 };
 
 // ---------------------------------------------------------------------------
@@ -420,8 +421,13 @@ struct RowPass {
             const elem *src = lds + row * ROW_LDS + row_pad(g);
             u64 *dst = base + (size_t)row * NPTS + g;
             if constexpr (TAP::ACTIVE) {
-                tap->out(row * NPTS + g, __builtin_bit_cast(u64, src[0]), c);
-                tap->out(row * NPTS + g + 1, __builtin_bit_cast(u64, src[1]), c);
+                if constexpr (TAP::STORES) {
+                    tap->store(row * NPTS + g, __builtin_bit_cast(u64, src[0]), __builtin_bit_cast(u64, src[1]));
+                    continue;
+                } else {
+                    tap->out(row * NPTS + g, __builtin_bit_cast(u64, src[0]), c);
+                    tap->out(row * NPTS + g + 1, __builtin_bit_cast(u64, src[1]), c);
+                }
             }
             if (STREAM && OUT_MODE == IO_CANONICAL) {
                 store_stream_u64(dst, __builtin_bit_cast(u64, src[0]));

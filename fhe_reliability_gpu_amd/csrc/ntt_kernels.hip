@@ -296,6 +296,7 @@ template <class A, bool IN, bool OUT>
 struct ChecksumTap {
     static constexpr bool ACTIVE = true;
     static constexpr bool MID = false;
+    static constexpr bool STORES = false;
     typedef typename A::elem elem;
     TwPtr win, wout;                   // ArithU64: Shoup-encoded weights of this limb, offset to the tile's first element
     const u64 FHE_GLOBAL *wout8;       // ArithF64: output-side weights as plain residues (the quotient factor is one multiply)
@@ -341,6 +342,7 @@ template <class A, int PASS>
 struct PhaseTap {
     static constexpr bool ACTIVE = true;
     static constexpr bool MID = PASS == 0;
+    static constexpr bool STORES = false;
     typedef typename A::elem elem;
     TwPtr win, umid, wout;             // ArithU64: Shoup-encoded weights of this limb, offset to the tile's first element
     const u64 FHE_GLOBAL *umid8, *wout8;   // ArithF64: the same weights as plain residues
@@ -714,6 +716,108 @@ hipError_t launch_polymul(hipStream_t st, const PassArgs &a, u64 *b, u64 *c, int
     if (e != hipSuccess) return e;
     if (logn >= 13) return launch_ntt(st, pc, logn, true, path, 1, 1);
     return hipSuccess;
+}
+
+// ---------------------------------------------------------------------------
+// Forward transform whose last pass ends in the mod-down / rescale tail instead of a plain store:
+//   out_h[l] = (a_h[l] - NTT(x_h[l])) * scal[l] (+ add_h[l])  mod q_l
+// (k_sub_scale's arithmetic, aux_kernels.hip, applied to the words the row pass is about to write: the transformed limbs
+// are never stored and re-read, and the separate launch disappears).  Units: [part h][limb l] of `a.data`.
+// ---------------------------------------------------------------------------
+struct SubScaleTap {
+    static constexpr bool ACTIVE = true;
+    static constexpr bool MID = false;
+    static constexpr bool STORES = true;
+    const u64 *acc, *add;       // offset to the tile's first element; add may be null
+    u64 *out;
+    u64 scal, q, r0, r1;
+    template <class E, class C> FHE_D void in(u32, E, const C &) {}
+    template <class C> FHE_D void out_(u32, u64, const C &) {}
+    FHE_D u64 one(u64 a, u64 x, const u64 *ad, u32 idx) const
+    {
+        const u64 av = a < q ? a : barrett128(a, 0, q, r0, r1);
+        const u64 d = av >= x ? av - x : av + q - x;
+        u64 v = barrett128(d * scal, mulhi64(d, scal), q, r0, r1);
+        if (ad) {
+            const u64 t = ad[idx];
+            v += t < q ? t : barrett128(t, 0, q, r0, r1);
+            v = v >= q ? v - q : v;
+        }
+        return v;
+    }
+    FHE_D void store(u32 idx, u64 x0, u64 x1)
+    {
+        const ulonglong2 a = *reinterpret_cast<const ulonglong2 *>(acc + idx);
+        ulonglong2 r;
+        r.x = one(a.x, x0, add, idx);
+        r.y = one(a.y, x1, add, idx + 1);
+        *reinterpret_cast<ulonglong2 *>(out + idx) = r;
+    }
+};
+
+template <class PASS, int LOGN>
+__global__ __launch_bounds__(NTT_THREADS) void k_ntt_row_subscale(PassArgs a, RowEpiArgs ep)
+{
+    typedef typename PASS::Arith A;
+    static_assert(PASS::STAGE_OUT, "the epilogue sits in the staged copy-out phase");
+    __shared__ __attribute__((aligned(16))) typename PASS::elem lds[PASS::LDS_ELEMS];
+    u32 limb, row0 = 0;
+    u64 *base = row_tile<PASS, LOGN>(blockIdx.x, a, limb, row0);
+    const u32 unit = blockIdx.x / PASS::TILES, polys = a.units / a.limbs, l = unit / polys, h = unit % polys;
+    const LimbParams &p = a.lp[limb];
+    const typename A::Ctx ctx = A::make_ctx(p);
+    const TwPtr tw = as_global(p.fwd);
+    const Tw inv_n = p.inv_n;
+    const int tid = threadIdx.x;
+    const size_t eoff = ((size_t)l << LOGN) + (size_t)row0 * PASS::NPTS;      // element offset inside part h
+    SubScaleTap tap{ep.a + (size_t)h * ep.a_stride + eoff, ep.add[h] ? ep.add[h] + eoff : nullptr, ep.out[h] + eoff, ep.scal[l], p.q, p.barrett_lo, p.barrett_hi};
+    const u64 *from = a.src ? a.src + (base - a.data) : nullptr;
+    PASS::template phase<0>(tid, base, lds, tw, row0, ctx, inv_n, &tap, from);
+    if constexpr (PASS::NPHASE > 1) {
+        __syncthreads();
+        PASS::template phase<1>(tid, base, lds, tw, row0, ctx, inv_n, &tap);
+    }
+    if constexpr (PASS::NPHASE > 2) {
+        __syncthreads();
+        PASS::template phase<2>(tid, base, lds, tw, row0, ctx, inv_n, &tap);
+    }
+    if constexpr (PASS::NPHASE > 3) {
+        __syncthreads();
+        PASS::template phase<3>(tid, base, lds, tw, row0, ctx, inv_n, &tap);
+    }
+}
+
+template <class A, int LOGN>
+static hipError_t launch_subscale_t(hipStream_t st, const PassArgs &a, const RowEpiArgs &ep)
+{
+    constexpr int GEO = LOGN >= 13 ? 1 : 0;
+    typedef Passes<A, LOGN, false, GEO> PS;
+    if constexpr (!PS::G::TWO_PASS) {
+        hipLaunchKernelGGL((k_ntt_row_subscale<typename PS::Single, LOGN>), dim3(a.units * PS::Single::TILES), dim3(NTT_THREADS), 0, st, a, ep);
+    } else {
+        hipError_t e = launch_pass<typename PS::Col, LOGN, false, true>(st, a);
+        if (e != hipSuccess) return e;
+        PassArgs second = a;
+        second.src = nullptr;
+        hipLaunchKernelGGL((k_ntt_row_subscale<typename PS::Row, LOGN>), dim3(a.units * PS::Row::TILES), dim3(NTT_THREADS), 0, st, second, ep);
+    }
+    return hipGetLastError();
+}
+
+bool ntt_subscale_supported(int logn) { return logn >= 5 && logn <= NTT_MAX_LOGN; }
+
+hipError_t launch_ntt_subscale(hipStream_t st, const PassArgs &a, const RowEpiArgs &ep, int logn, int path)
+{
+    if (a.units == 0) return hipSuccess;
+    if (a.map || !ntt_subscale_supported(logn) || a.units / a.limbs > 3) return hipErrorInvalidValue;
+    switch (logn) {
+#define FHE_CASE(L) \
+    case L: return path == PATH_F64 ? launch_subscale_t<ArithF64, L>(st, a, ep) : launch_subscale_t<ArithU64, L>(st, a, ep);
+        FHE_CASE(5) FHE_CASE(6) FHE_CASE(7) FHE_CASE(8) FHE_CASE(9) FHE_CASE(10) FHE_CASE(11) FHE_CASE(12) FHE_CASE(13)
+        FHE_CASE(14) FHE_CASE(15) FHE_CASE(16) FHE_CASE(17) FHE_CASE(18) FHE_CASE(19) FHE_CASE(20)
+#undef FHE_CASE
+    default: return hipErrorInvalidValue;
+    }
 }
 
 // ---------------------------------------------------------------------------

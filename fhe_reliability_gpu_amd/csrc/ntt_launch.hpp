@@ -18,6 +18,19 @@ hipError_t launch_ntt(hipStream_t st, const PassArgs &a, int logn, bool inverse,
 bool ntt_gs_supported(int logn);
 hipError_t launch_ntt_gs(hipStream_t st, const PassArgs &a, u64 *tmp, int logn, int path);
 
+// Forward transform of a.data = [parts <= 3][limbs][N] whose last pass writes out_h[l] = (a_h[l] - NTT(data_h[l])) * scal[l]
+// (+ add_h[l]) mod q_l instead of the transformed words (mod-down / rescale tail fused into the row pass); a_h = a + h * a_stride
+// words, out / add per part, scal per limb of the run (ntt_kernels.hip k_ntt_row_subscale).  a.data is scratch afterwards.
+struct RowEpiArgs {
+    u64 *out[3];
+    const u64 *add[3];
+    const u64 *a;
+    u64 a_stride;
+    const u64 *scal;
+};
+bool ntt_subscale_supported(int logn);
+hipError_t launch_ntt_subscale(hipStream_t st, const PassArgs &a, const RowEpiArgs &ep, int logn, int path);
+
 // c = a * b mod (x^N + 1, q_l): forward column passes, one launch that finishes both forward transforms,
 // multiplies and starts the inverse, inverse column pass.  a and b are scratch afterwards.
 bool polymul_fused_supported(int logn);
