@@ -50,6 +50,26 @@ def _py_ntt_task(args):
     return time.perf_counter() - t
 
 
+def host_cores():
+    """Host cores this process may use: the affinity mask, capped by the cgroup CPU quota (a GPU box hands a job a share of its
+    cores, not the whole socket)."""
+    n = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
+    for path in ("/sys/fs/cgroup/cpu.max", "/sys/fs/cgroup/cpu/cpu.cfs_quota_us"):
+        try:
+            txt = open(path).read().split()
+            if path.endswith("cpu.max"):
+                if txt[0] != "max":
+                    n = min(n, max(1, int(float(txt[0]) / float(txt[1]) + 0.5)))
+            else:
+                q = int(txt[0])
+                if q > 0:
+                    n = min(n, max(1, int(q / int(open("/sys/fs/cgroup/cpu/cpu.cfs_period_us").read()) + 0.5)))
+            break
+        except Exception:
+            continue
+    return n
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -62,6 +82,7 @@ def main():
     ap.add_argument("--check", action="store_true", help="verify one limb against the oracle before timing")
     ap.add_argument("--mode", choices=["fused", "twopass"], default="twopass")
     ap.add_argument("--no-extras", action="store_true", help="skip the secondary measurements (other batch shapes, composites)")
+    ap.add_argument("--chunk-mib", type=int, default=64, help="sub-batch size of each library call (0 = whole slab per launch pair)")
     ap.add_argument("--streams", type=int, default=2,
                     help="HIP streams the batch's polynomials are sharded over inside one GPU (each step = one call per stream)")
     args = ap.parse_args()
@@ -87,6 +108,9 @@ def main():
 
     eng = F.Engine(local_rank)
     eng.set_option("ntt_mode", 1 if args.mode == "fused" else 0)
+    # each library call transforms its slab as sub-batches of this size, so that a sub-batch's second launch finds the first
+    # one's output in the 256 MiB Infinity Cache (profiles/r02_variant_sweep.txt: 64 MiB is the best size with two streams)
+    eng.set_option("ntt_chunk_mib", args.chunk_mib)
     qs = F.create_moduli(N, [args.bits] * args.limbs)
     tables = eng.tables(LOGN, qs)
     units = args.polys * args.limbs
@@ -185,8 +209,9 @@ def main():
                         f"({batch_mib} MiB, {'exceeds' if streaming else 'fits'} the 256 MiB Infinity Cache), in place, resident on the device "
                         f"before the timed region",
             "log_n": LOGN, "limbs": args.limbs, "polys_per_gpu": args.polys, "prime_bits": args.bits,
-            "parallelism": f"limb-polynomials sharded over {world} GPU(s), no collective; {n_str} stream(s) per GPU",
-            "streams_per_gpu": n_str,
+            "parallelism": f"limb-polynomials sharded over {world} GPU(s), no collective; {n_str} stream(s) per GPU, "
+                           f"each call in sub-batches of {args.chunk_mib} MiB",
+            "streams_per_gpu": n_str, "chunk_mib": args.chunk_mib,
         },
         "roofline": {
             "bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
@@ -214,19 +239,33 @@ def main():
         torch.cuda.synchronize()
         return a0.elapsed_time(a1) / steps
 
-    # each kernel of the step timed on its own, inside real transforms on ONE stream: a block of column-pass launches and a
-    # block of row-pass launches over the same batch (each moves the batch once in and once out: 16*N bytes per
-    # limb-polynomial per LAUNCH; the transform needs both).  Always >= 200 launches per block, whatever --steps is; the
-    # rocprofv3 kernel trace of this command (profiles/) must agree with these averages.
+    # each kernel of the step timed on its own, inside real transforms on ONE stream (column pass, event, row pass, event, ...:
+    # the sequence the transform runs; each launch moves the batch once in and once out, 16*N bytes per limb-polynomial per
+    # LAUNCH; the transform needs both).  Always 200 transforms, whatever --steps is; the rocprofv3 kernel trace of this command
+    # (profiles/) must agree with these averages.
     if args.mode == "twopass" and rank == 0:
+        marks = []
+        for i in range(220):
+            ev = [torch.cuda.Event(enable_timing=True) for _ in range(3)]
+            eng.set_option("ntt_only_pass", 0)
+            ev[0].record(stream)
+            step()
+            ev[1].record(stream)
+            eng.set_option("ntt_only_pass", 1)
+            step()
+            ev[2].record(stream)
+            if i >= 20:
+                marks.append(ev)
+        eng.set_option("ntt_only_pass", -1)
+        torch.cuda.synchronize()
         per_launch = {}
         for k, name in ((0, "column_pass"), (1, "row_pass")):
-            eng.set_option("ntt_only_pass", k)
-            ms = timed_loop(step, 200, 20)
-            per_launch[name] = {"avg_launch_ms": ms, "launches_timed": 200, "GBps_moved": alg_bytes_per_step / (ms * 1e-3) / 1e9,
+            ms = sum(e[k].elapsed_time(e[k + 1]) for e in marks) / len(marks)
+            per_launch[name] = {"avg_launch_ms": ms, "launches_timed": len(marks), "GBps_moved": alg_bytes_per_step / (ms * 1e-3) / 1e9,
                                 "frac_of_peak": alg_bytes_per_step / (ms * 1e-3) / 1e9 / HBM_PEAK_GBS}
-        eng.set_option("ntt_only_pass", -1)
         result["roofline"]["per_launch"] = per_launch
+        result["roofline"]["per_launch_note"] = ("whole-batch launches (no sub-batching) inside real transforms on one stream, 200 transforms, an event "
+                                                 "between the two launches; each launch moves the batch once in and once out")
         one_stream_ms = timed_loop(step, 200, 20)
         result["roofline"]["ms_per_step_one_stream"] = one_stream_ms
     else:
@@ -391,20 +430,19 @@ def main():
         also.update(composite_rates())
 
         def fourstep_rate():
-            # four_step_ntt (reliability_test/four_step_ntt_prot.py:71-109) at 2^16 = 256 x 256 and 2^17 = 512 x 256, MOD = 998244353
+            # four_step_ntt (reliability_test/four_step_ntt_prot.py:71-109), MOD = 998244353, as a batch: two launches for all
+            # vectors; 2^16 = 256 x 256 and 2^17 = 512 x 256 (the n1 != n2 case of BASELINE configs[3]); 16 N bytes per vector
             out = {}
-            for n1, n2 in ((256, 256), (512, 256)):
+            for n1, n2, n_vec in ((256, 256, 1), (256, 256, 256), (256, 256, 1024), (512, 256, 512)):
                 nn = n1 * n2
-                if (998244353 - 1) % nn:
-                    continue
                 h = C.c_void_p()
                 check(lib.fhe_fourstep_create(eng._h, n1, n2, 998244353, 3, C.byref(h)))
-                src = torch.randint(0, 998244353, (nn,), generator=g, device="cuda", dtype=torch.int64)
-                dst = torch.empty_like(src)
-                ms = timed_loop(lambda: check(lib.fhe_fourstep_ntt(eng._h, P(dst), P(src), h, sptr)), 200, 20)
-                out[f"fourstep_{n1}x{n2}_single_vector"] = {"us_per_call_device": ms * 1e3,
-                                                            "frac_of_hbm_roofline (16N bytes)": 16.0 * nn / (ms * 1e-3) / 1e9 / HBM_PEAK_GBS}
+                src = torch.randint(0, 998244353, (n_vec, nn), generator=g, device="cuda", dtype=torch.int64)
+                ms = timed_loop(lambda: check(lib.fhe_fourstep_ntt_batch(eng._h, P(src), P(src), h, n_vec, sptr)), 100, 10)
+                out[f"fourstep_{n1}x{n2}_batch{n_vec}"] = {"us_per_call_device": ms * 1e3, "vectors_per_s": n_vec / (ms * 1e-3),
+                                                         "frac_of_hbm_roofline (16N bytes per vector)": 16.0 * nn * n_vec / (ms * 1e-3) / 1e9 / HBM_PEAK_GBS}
                 lib.fhe_fourstep_destroy(h)
+                del src
             return out
         also.update(fourstep_rate())
 
@@ -503,7 +541,7 @@ def main():
     if rank == 0 and world == 1 and not args.no_cpu:
         from oracle import cport as O
         from oracle import pyport as PY
-        cores = os.cpu_count() or 1
+        cores = host_cores()
         rp = O.root_powers(qs[0], LOGN)
         a = first_limb.cpu().numpy().view(np.uint64)
         # (1) the C port on ONE core: the scalar restatement (u128 mulmod), ~5 s
@@ -538,11 +576,12 @@ def main():
         try:
             import multiprocessing as mp
             ctx = mp.get_context("spawn")       # workers never touch the GPU; spawn keeps them clear of this process's HIP state
-            with ctx.Pool(cores) as pool:
-                pool.map(_py_ntt_task, [(a_list[:256], qs[0], rp_list[:256], 1)] * cores)      # start the workers (untimed)
+            workers = min(cores, 64)             # one process per core, bounded (the GPU box caps processes per job)
+            with ctx.Pool(workers) as pool:
+                pool.map(_py_ntt_task, [(a_list[:256], qs[0], rp_list[:256], 1)] * workers)    # start the workers (untimed)
                 t = time.perf_counter()
-                pool.map(_py_ntt_task, [(a_list, qs[0], rp_list, 1)] * (2 * cores))
-                py_all = 2 * cores / (time.perf_counter() - t)
+                pool.map(_py_ntt_task, [(a_list, qs[0], rp_list, 1)] * (2 * workers))
+                py_all = 2 * workers / (time.perf_counter() - t)
         except Exception as ex:
             py_all = repr(ex)
         # (5) BASELINE configs[0]: N = 2^12, one 61-bit prime, cyclic NTT with motivation/ntt.py semantics (generator root)
@@ -563,11 +602,11 @@ def main():
             "one_core": {"value": c1, "unit": "NTT/s", "cores": 1, "sample": f"{reps} forward NTTs of one N=2^16 limb (orc_nwt_forward), ~5 s"},
             "pure_python_one_core": {"value": py1, "unit": "NTT/s", "cores": 1,
                                      "sample": f"{py_reps} forward NTTs of the same limb with oracle/pyport.py nwt_forward (Python integers, the reference's CPU form)"},
-            "pure_python_all_cores": {"value": py_all, "unit": "NTT/s", "cores": cores,
-                                      "sample": f"{2 * cores} independent limbs over multiprocessing.Pool({cores}), same function"},
+            "pure_python_all_cores": {"value": py_all, "unit": "NTT/s", "cores": min(cores, 64),
+                                      "sample": f"{2 * min(cores, 64)} independent limbs over multiprocessing.Pool({min(cores, 64)}), same function"},
             "config0_N=2^12_61bit_cyclic_python": {"value": c0_py, "unit": "NTT/s", "cores": 1,
                                                    "sample": f"{r12} cyclic NTTs (oracle/pyport.py ntt_cyclic = motivation/ntt.py:8-32 semantics), q61={q61}, root={root}"},
-            "host_cores": cores,
+            "host_cores": cores, "host_cores_note": "affinity mask capped by the cgroup CPU quota; os.cpu_count() = " + str(os.cpu_count()),
         }
     if rank == 0:
         print(json.dumps(result))

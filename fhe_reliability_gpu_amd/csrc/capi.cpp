@@ -110,7 +110,11 @@ int ntt_batch(fhe_ctx *ctx, u64 *d, const fhe_ntt_tables *t, size_t n_poly, size
             if (ctl->bytes < need) {
                 // growing frees the old block: make sure no launch on this stream still uses it
                 HIP_TRY(hipStreamSynchronize(st));
+                u32 carried = 0;       // an error word set by an earlier launch moves to the new block
+                if (ctl->p) HIP_TRY(hipMemcpy(&carried, ctl->as<u32>() + fused_error_word(), sizeof carried, hipMemcpyDeviceToHost));
                 HIP_TRY(ctl->alloc(need * 2));
+                HIP_TRY(hipMemset(ctl->p, 0, need * 2));
+                if (carried) HIP_TRY(hipMemcpy(ctl->as<u32>() + fused_error_word(), &carried, sizeof carried, hipMemcpyHostToDevice));
             }
             e = launch_ntt_fused(st, a, t->log_n, inverse, path, ctl->as<u32>(), ctx->fused_dist, ctx->fused_wgs, ctx->fused_variant, ctx->fused_skip_teams);
         } else if (ctx->fault_idx >= 0 && t->log_n >= 13) {
@@ -289,7 +293,10 @@ int fhe_ctx_check(fhe_ctx *ctx)
         HIP_TRY(hipStreamSynchronize(kv.first));
         u32 flag = 0;
         HIP_TRY(hipMemcpy(&flag, kv.second->as<u32>() + fused_error_word(), sizeof flag, hipMemcpyDeviceToHost));
-        if (flag) return fail(FHE_ERR_HIP, "fused NTT: a bounded wait ran out (results of that launch are invalid)");
+        if (flag) {
+            HIP_TRY(hipMemset(kv.second->as<u32>() + fused_error_word(), 0, sizeof flag));      // reported once
+            return fail(FHE_ERR_HIP, "fused NTT: a bounded wait ran out in a launch since the last check (its results are invalid)");
+        }
     }
     return FHE_OK;
 }

@@ -228,13 +228,17 @@ bool fused_supported(int logn) { return logn >= 13 && logn <= 17; }
 
 size_t fused_ctl_bytes(u32 units) { return fused_ctl_words(units) * sizeof(u32); }
 
-// ctl must hold fused_ctl_bytes(units) bytes; it is zeroed on the stream first.
+// ctl must hold fused_ctl_bytes(units) bytes; its counters are zeroed on the stream first.  The error word is NOT: it stays
+// set from the launch whose bounded wait ran out until the host reads and clears it (fhe_ctx_check), so a later launch on
+// the same stream cannot hide an earlier failure.  (The owner zeroes the whole block once when it allocates it.)
 hipError_t launch_ntt_fused(hipStream_t st, const PassArgs &a, int logn, bool inverse, int path, u32 *ctl, u32 dist, u32 wgs,
                             int variant, u32 skip_teams)
 {
     if (a.units == 0) return hipSuccess;
     if (!fused_supported(logn) || dist < 1) return hipErrorInvalidValue;
-    hipError_t e = hipMemsetAsync(ctl, 0, fused_ctl_bytes(a.units), st);
+    hipError_t e = hipMemsetAsync(ctl, 0, (size_t)fused_error_word() * sizeof(u32), st);
+    if (e != hipSuccess) return e;
+    e = hipMemsetAsync(ctl + fused_base(), 0, fused_ctl_bytes(a.units) - (size_t)fused_base() * sizeof(u32), st);
     if (e != hipSuccess) return e;
     FusedArgs f{a, ctl, fused_maxg(a.units), dist, skip_teams};
     return path == PATH_F64 ? launch_fused_size<ArithF64>(st, f, logn, inverse, wgs, variant)

@@ -40,9 +40,9 @@ constexpr u32 FUSED_LINE = 32;          // u32 words per 128-byte line
 
 enum { HANDOFF_SC1 = 1, HANDOFF_NT = 2, HANDOFF_ACQUIRE = 3 };
 
-// Control block layout (u32 words), zeroed before every launch:
+// Control block layout (u32 words); the counters are zeroed before every launch, the error flag only by the host:
 //   [LINE*x]                 ticket counter of team x
-//   [LINE*TEAMS]             error flag (a bounded spin ran out / inconsistent state)
+//   [LINE*TEAMS]             error flag (a bounded spin ran out / inconsistent state), sticky until fhe_ctx_check reads it
 //   done[x][g] : finished first-pass tiles of team x's limb g   at  base + x*maxg + g
 //   fin[u]     : finished second-pass tiles of limb u           at  base + TEAMS*maxg + u
 FHE_HD constexpr u32 fused_ticket_word(u32 x) { return FUSED_LINE * x; }

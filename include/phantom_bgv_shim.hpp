@@ -252,7 +252,6 @@ public:
         for (auto &kv : levels_) {
             fhe_keyswitch_destroy(kv.second.ks);
             fhe_baseconv_destroy(kv.second.to_plain);
-            fhe_baseconv_destroy(kv.second.last_to_rest);
             if (kv.second.tables != full_) fhe_ntt_tables_destroy(kv.second.tables);
         }
         fhe_ntt_tables_destroy(plain_);
@@ -263,7 +262,6 @@ public:
         fhe_ntt_tables *tables = nullptr;     // [q_0 .. q_{l-1}, p_0 .. p_{K-1}]
         fhe_keyswitch *ks = nullptr;
         fhe_baseconv *to_plain = nullptr;     // Q_l -> {t}
-        fhe_baseconv *last_to_rest = nullptr; // {q_{l-1}} -> q_0 .. q_{l-2}
         std::vector<uint64_t> half_mod_q;     // floor(Q_l / 2) mod q_j
         uint64_t half_mod_t = 0;
     };
@@ -281,7 +279,6 @@ public:
         must(fhe_keyswitch_create(ctx, lv.tables, (int)l, (int)K_, (int)l, &lv.ks), "keyswitch plan");
         must(fhe_keyswitch_set_plain_modulus(lv.ks, t_), "keyswitch plain modulus");
         must(fhe_baseconv_create(ctx, primes_.data(), (int)l, &t_, 1, &lv.to_plain), "decrypt conversion");
-        if (l >= 2) must(fhe_baseconv_create(ctx, &primes_[l - 1], 1, primes_.data(), (int)l - 1, &lv.last_to_rest), "mod-switch conversion");
         Big Q;
         for (size_t j = 0; j < l; j++) Q.mul(primes_[j]);
         Q.half();
@@ -597,10 +594,8 @@ inline PhantomCiphertext multiply(const PhantomContext &c, const PhantomCipherte
     fhe_ntt_tables *tab = c.full_tables();
     PhantomCiphertext r;
     r.resize(3, l, c.n());
-    must(fhe_modmul(ctx, r.part(0), x.part(0), y.part(0), tab, 1, l, 0, nullptr), "d0");
-    must(fhe_modmul(ctx, r.part(1), x.part(0), y.part(1), tab, 1, l, 0, nullptr), "d1");
-    must(fhe_modmul_acc(ctx, r.part(1), x.part(1), y.part(0), tab, 1, l, 0, nullptr), "d1+");
-    must(fhe_modmul(ctx, r.part(2), x.part(1), y.part(1), tab, 1, l, 0, nullptr), "d2");
+    // one pass over the four parts: d0 = x0 y0, d1 = x0 y1 + x1 y0, d2 = x1 y1
+    must(fhe_tensor_product(ctx, r.part(0), r.part(1), r.part(2), x.part(0), x.part(1), y.part(0), y.part(1), tab, l, 0, nullptr), "tensor product");
     r.correction = mulmod(x.correction, y.correction, c.t());
     return r;
 }
@@ -612,13 +607,11 @@ inline void relinearize_inplace(const PhantomContext &c, PhantomCiphertext &ct, 
     auto *ctx = phantom::detail::engine();
     const size_t l = ct.coeff_modulus_size(), N = c.n();
     const PhantomContext::Level &lv = c.level(l);
-    DevPoly k0(l * N), k1(l * N);
-    must(fhe_keyswitch_apply(ctx, lv.ks, k0.p, k1.p, ct.part(2), key_at_level(c, rk.key, l), nullptr), "relinearize");
     PhantomCiphertext r;
     r.resize(2, l, N);
     r.correction = ct.correction;
-    must(fhe_modadd(ctx, r.part(0), ct.part(0), k0.p, c.full_tables(), 1, l, 0, nullptr), "c0");
-    must(fhe_modadd(ctx, r.part(1), ct.part(1), k1.p, c.full_tables(), 1, l, 0, nullptr), "c1");
+    // key switch of the degree-2 part; d0 and d1 are added by the key switch's last launch
+    must(fhe_relinearize(ctx, lv.ks, r.part(0), r.part(1), ct.part(0), ct.part(1), ct.part(2), key_at_level(c, rk.key, l), nullptr), "relinearize");
     must(fhe_sync(ctx, nullptr), "sync");
     ct = std::move(r);
 }
@@ -631,27 +624,12 @@ inline void mod_switch_to_next_inplace(const PhantomContext &c, PhantomCiphertex
     const size_t l = ct.coeff_modulus_size(), N = c.n(), last = l - 1;
     if (l < 2) throw std::invalid_argument("no prime left to drop");
     const PhantomContext::Level &lv = c.level(l);
-    fhe_ntt_tables *tab = c.full_tables();
     const uint64_t ql = c.primes()[last], t = c.t();
-    const uint64_t tinv = invmod_prime(t % ql, ql);
-    std::vector<uint64_t> tmod(last), qinv(last);
-    for (size_t j = 0; j < last; j++) {
-        tmod[j] = t % c.primes()[j];
-        qinv[j] = invmod_prime(ql % c.primes()[j], c.primes()[j]);
-    }
     PhantomCiphertext r;
     r.resize(ct.size(), last, N);
-    DevPoly y(N), delta(last * N);
-    for (size_t i = 0; i < ct.size(); i++) {
-        must(fhe_d2d(ctx, y.p, ct.part(i) + last * N, N * 8, nullptr), "last limb");
-        must(fhe_ntt_inverse_inplace(ctx, y.p, tab, 1, last, nullptr), "intt");
-        must(fhe_scalar_affine(ctx, y.p, y.p, &tinv, nullptr, tab, 1, 1, last, nullptr), "* t^-1");
-        must(fhe_baseconv_exact(ctx, delta.p, y.p, lv.last_to_rest, N, nullptr), "to the other primes");
-        must(fhe_scalar_affine(ctx, delta.p, delta.p, tmod.data(), nullptr, tab, 1, last, 0, nullptr), "* t");
-        must(fhe_ntt_forward_inplace(ctx, delta.p, tab, last, 0, nullptr), "ntt");
-        must(fhe_modsub(ctx, r.part(i), ct.part(i), delta.p, tab, 1, last, 0, nullptr), "c - delta");
-        must(fhe_scalar_affine(ctx, r.part(i), r.part(i), qinv.data(), nullptr, tab, 1, last, 0, nullptr), "/ q_last");
-    }
+    // every part in one call: INTT of the last limbs, their residues (times t [. t^-1]: BGV), NTT with the subtraction and
+    // the division by q_last riding on its last pass
+    must(fhe_rescale(ctx, lv.ks, r.data(), ct.data(), ct.size(), nullptr), "mod switch");
     must(fhe_sync(ctx, nullptr), "sync");
     r.correction = mulmod(ct.correction, ql % t, t);   // plaintext became m q_last^-1: undo at decryption
     ct = std::move(r);
