@@ -827,6 +827,8 @@ hipError_t launch_ntt_subscale(hipStream_t st, const PassArgs &a, const RowEpiAr
 // tile in LDS (the digit's own limbs take the NTT-form input c instead), each thread then picks up its 16-byte pairs of the
 // finished tile where the copy-out phase would, multiplies by the two key halves and adds into registers.  After the last
 // digit the two sums are written once.  Exact integer arithmetic in both paths: the result equals k_ks_mac's word for word.
+// The 64 registers of sums put the kernel at two workgroups per CU; a variant with one key half per workgroup (32 registers of
+// sums, the row passes run twice) measured 15-30 % slower at every shape (profiles/r02_ks_variants.txt) and is not kept.
 // ---------------------------------------------------------------------------
 template <class A, int LOGN, int GEO>
 __global__ __launch_bounds__(NTT_THREADS, 2) void k_ks_rowmac(KsMacArgs a)
@@ -961,9 +963,7 @@ bool ntt_packed_supported(int logn, bool inverse, int path)
 }
 size_t ntt_packed_scratch_words() { return (size_t)256 * PK_BLOCK_WORDS; }
 
-// (Chunking large batches so that the second launch would find the first launch's output in the
-// Infinity Cache was measured and brings nothing: a 512 MiB batch runs at the HBM-streaming rate
-// either way, and splitting costs launches.  One launch pair per call.)
+// (Batches larger than the Infinity Cache are cut into sub-batches by the caller, capi.cpp ntt_batch: one launch pair each.)
 hipError_t launch_ntt(hipStream_t st, const PassArgs &a, int logn, bool inverse, int path, int geo, int which, bool resident)
 {
     if (a.units == 0) return hipSuccess;
