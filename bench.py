@@ -278,7 +278,7 @@ def main():
     if os.path.exists(tpath):
         with open(tpath) as fh:
             tr = json.load(fh)
-        key = f"{args.mode}:limbs={args.limbs}:polys={args.polys}:bits={args.bits}"
+        key = f"{args.mode}:limbs={args.limbs}:polys={args.polys}:bits={args.bits}:chunk={args.chunk_mib}:streams={n_str}"
         if key in tr:
             result["roofline"]["traffic"] = tr[key]["bytes_per_step"]
             result["roofline"]["traffic_note"] = tr[key]["note"]
