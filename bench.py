@@ -18,9 +18,10 @@ distinct primes per polynomial (configs[2] shape).
 Multi-GPU: residue polynomials are independent, so every rank transforms its own batch
 (weak scaling, no collective on the data path, `value` = all ranks' NTTs / max time).  The
 path's one exchange -- the base-conversion join of key switching -- is measured by the
-strong-scaling leg `also.strong_scaling_config5` (BASELINE configs[4]: N = 2^16, L = 44
-limbs sharded over the ranks, two RCCL all-gathers per rotation, compute and joins timed
-separately).
+strong-scaling legs `also.strong_scaling_config5` (BASELINE configs[4]: a rotation at
+N = 2^16, L = 44) and `also.strong_scaling_config4` (configs[3]: hmult at N = 2^17, L = 32), limbs
+sharded over the ranks, two RCCL all-gathers per key switch and one broadcast per rescale,
+compute and joins timed separately.
 
 Prints ONE JSON line on rank 0 (contract in the task statement) with `roofline`
 (algorithmic bytes 16*N per limb-NTT / HIP-event time vs 8 TB/s) and `cpu_baseline`
@@ -96,7 +97,14 @@ def main():
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
-        dist.init_process_group(backend="nccl", device_id=torch.device("cuda", local_rank))
+        # RCCL; FHE_BENCH_BACKEND=gloo + FHE_BENCH_ONE_GPU=1 rehearse the multi-rank path on a one-GPU box (not a measurement)
+        backend = os.environ.get("FHE_BENCH_BACKEND", "nccl")
+        if os.environ.get("FHE_BENCH_ONE_GPU"):
+            local_rank = 0
+        if backend == "nccl":
+            dist.init_process_group(backend="nccl", device_id=torch.device("cuda", local_rank))
+        else:
+            dist.init_process_group(backend=backend)
     torch.cuda.set_device(local_rank)
 
     import ctypes as C
@@ -484,13 +492,14 @@ def main():
 
     # ------------------------------------------------------------------ strong scaling: config 5 with the limbs sharded
     if extras:
-        def strong_scaling():
-            # BASELINE configs[4]: one rotation at N = 2^16, L = 44, K = 11, dnum = 4 with the limbs sharded over the ranks
-            # (fhe_keyswitch_shard_* phases on each GPU, two in-place RCCL all-gathers: dist.sharded_rotate).  Total work is
-            # fixed as the rank count grows; per call: the three compute phases and the two joins from CUDA events on this
-            # rank's stream, max over ranks.
-            from fhe_reliability_gpu_amd.dist import ShardedKeySwitch, ks_layout, sharded_rotate
-            logn, L, K, dnum, reps = 16, 44, 11, 4, 20
+        def strong_scaling(kind):
+            # BASELINE configs[4] (kind "rotate": one rotation at N = 2^16, L = 44, K = 11, dnum = 4) and configs[3] (kind "hmult":
+            # multiply + relinearize + rescale at N = 2^17, L = 32, K = 8, dnum = 4) with the limbs sharded over the ranks: the
+            # fhe_keyswitch_shard_* / fhe_rescale_shard_* phases on each GPU, two in-place RCCL all-gathers per key switch and one
+            # broadcast per rescale (dist.sharded_rotate / sharded_hmult).  Total work is fixed as the rank count grows; per call:
+            # the compute phases and the joins from CUDA events on this rank's stream, max over ranks.
+            from fhe_reliability_gpu_amd.dist import ShardedKeySwitch, ks_layout, sharded_hmult, sharded_rotate
+            logn, L, K, dnum, reps = (16, 44, 11, 4, 20) if kind == "rotate" else (17, 32, 8, 4, 10)
             n = 1 << logn
             qk = F.create_moduli(n, [args.bits] * (L + K))
             tk = eng.tables(logn, qk)
@@ -499,41 +508,60 @@ def main():
             gg = torch.Generator(device="cuda")
             gg.manual_seed(7 + rank)
             mk = lambda *shape: torch.randint(0, qk[0], shape, generator=gg, device="cuda", dtype=torch.int64)
-            c0, c1, gk = mk(lay["cn"], n), mk(lay["cn"], n), mk(dnum, 2, mo, n)
+            c0, c1, b0, b1, gk = mk(lay["cn"], n), mk(lay["cn"], n), mk(lay["cn"], n), mk(lay["cn"], n), mk(dnum, 2, mo, n)
             plan = ShardedKeySwitch(eng, tk, L, K, dnum)
+            if kind == "rotate":
+                call = lambda tm=None: sharded_rotate(plan, c0, c1, 3, gk, timings=tm)
+            else:
+                call = lambda tm=None: sharded_hmult(plan, c0, c1, b0, b1, gk, rescale=True, timings=tm)
             with torch.cuda.stream(stream):
                 for _ in range(3):
-                    sharded_rotate(plan, c0, c1, 3, gk)
+                    call()
                 barrier()
                 tm = {}
+                e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
                 tw = time.perf_counter()
+                e0.record()
                 for _ in range(reps):
-                    sharded_rotate(plan, c0, c1, 3, gk, timings=tm)
+                    call(tm)
+                e1.record()
                 barrier()
                 wall_c = (time.perf_counter() - tw) / reps
             evs = tm["events"]
             seg = [sum(e[i].elapsed_time(e[i + 1]) for e in evs) / len(evs) for i in range(5)]
-            vals = torch.tensor([seg[0] + seg[2] + seg[4], seg[1], seg[3], sum(seg), wall_c * 1e3], device="cuda", dtype=torch.float64)
+            bc = 0.0
+            if "rescale_events" in tm:
+                bc = sum(e[1].elapsed_time(e[2]) for e in tm["rescale_events"]) / len(tm["rescale_events"])
+            tot = e0.elapsed_time(e1) / reps
+            vals = torch.tensor([tot - seg[1] - seg[3] - bc, seg[1], seg[3], bc, tot, wall_c * 1e3], device="cuda", dtype=torch.float64)
             if world > 1:
                 dist.all_reduce(vals, op=dist.ReduceOp.MAX)
-            comp, j1, j2, tot, wl = (float(x) for x in vals.tolist())
-            ntt_count = L + dnum * (L + K) - L + 2 * K + 2 * L
-            return {"strong_scaling_config5": {
-                "workload": f"one rotation, N=2^16, L={L}, K={K}, dnum={dnum}, limbs sharded over {world} rank(s) "
+            comp, j1, j2, jb, tot, wl = (float(x) for x in vals.tolist())
+            ntt_count = L + dnum * (L + K) - L + 2 * K + 2 * L + (2 + 2 * (L - 1) if kind == "hmult" else 0)
+            name = "strong_scaling_config5" if kind == "rotate" else "strong_scaling_config4"
+            what = "one rotation" if kind == "rotate" else "one hmult (multiply + relinearize + rescale)"
+            out = {
+                "workload": f"{what}, N=2^{logn}, L={L}, K={K}, dnum={dnum}, limbs sharded over {world} rank(s) "
                             f"(rank 0 owns {lay['cn']} ciphertext + {lay['sn']} special limbs)",
                 "scaling": "strong", "n_gpus": world, "backend": (dist.get_backend() if world > 1 else "none (1 rank: no collective issued)"),
-                "us_per_rotation_device": tot * 1e3, "us_per_rotation_wall": wl * 1e3,
+                "us_per_call_device": tot * 1e3, "us_per_call_wall": wl * 1e3,
                 "us_compute_phases": comp * 1e3, "us_all_gather_1 (input, coefficient form)": j1 * 1e3,
                 "us_all_gather_2 (special limbs of both halves)": j2 * 1e3,
                 "bytes_all_gather_1_per_rank": plan.rows1 * n * 8, "bytes_all_gather_2_per_rank": plan.rows2 * n * 8,
-                "limb_ntts_per_rotation": ntt_count, "limb_ntt_per_s": ntt_count / (tot * 1e-3)}}
-        try:
-            ss = strong_scaling()
-            if rank == 0:
-                also.update(ss)
-        except Exception as ex:       # the headline must survive a failure of this leg; it is reported, not hidden
-            if rank == 0:
-                also["strong_scaling_config5"] = {"error": repr(ex)}
+                "limb_ntts_per_call": ntt_count, "limb_ntt_per_s": ntt_count / (tot * 1e-3)}
+            if kind == "hmult":
+                out["us_broadcast (last limbs of both parts)"] = jb * 1e3
+                out["bytes_broadcast"] = 2 * n * 8
+            del plan
+            return {name: out}
+        for kind in ("rotate", "hmult"):
+            try:
+                ss = strong_scaling(kind)
+                if rank == 0:
+                    also.update(ss)
+            except Exception as ex:       # the headline must survive a failure of this leg; it is reported, not hidden
+                if rank == 0:
+                    also["strong_scaling_" + kind] = {"error": repr(ex)}
     if rank == 0 and also:
         result["also"] = also
 

@@ -92,7 +92,10 @@ _SIG = {
     "fhe_keyswitch_create": (ci, [vp, vp, ci, ci, ci, C.POINTER(vp)]),
     "fhe_keyswitch_destroy": (ci, [vp]),
     "fhe_keyswitch_shard_layout": (ci, [ci, ci, ci, ci, C.POINTER(ci)]),
-    "fhe_keyswitch_create_sharded": (ci, [vp, vp, ci, ci, ci, ci, ci, vp, vp, C.POINTER(vp)]),
+    "fhe_keyswitch_create_sharded": (ci, [vp, vp, ci, ci, ci, ci, ci, vp, vp, vp, C.POINTER(vp)]),
+    "fhe_rescale_shard_info": (ci, [vp, C.POINTER(ci), C.POINTER(ci)]),
+    "fhe_rescale_shard_begin": (ci, [vp, vp, vp, sz, vp]),
+    "fhe_rescale_shard_finish": (ci, [vp, vp, vp, vp, sz, vp]),
     "fhe_keyswitch_shard_begin": (ci, [vp, vp, vp, vp]),
     "fhe_keyswitch_shard_inner": (ci, [vp, vp, vp, vp, vp]),
     "fhe_keyswitch_shard_finish": (ci, [vp, vp, vp, vp, vp, vp, vp]),

@@ -35,54 +35,79 @@ int fhe_relinearize(fhe_ctx *ctx, fhe_keyswitch *p, uint64_t *d_out0, uint64_t *
 
 // (c - [c]_{q_last}) / q_last on every part: INTT of the last limb, its residues modulo the remaining primes, NTT,
 // subtract, times q_last^-1.  BGV (plain modulus t set on the plan): the removed part is t * [c t^-1]_{q_last}.
-// d_in = [n_parts][L][N]; part i goes to outs[i] ([L-1][N]).
-static int rescale_core(fhe_ctx *ctx, fhe_keyswitch *p, uint64_t *const *outs, const uint64_t *d_in, size_t n_parts, void *stream)
+// d_in = [n_parts][cn][N] (the rows this rank owns; one device: cn = L).  Two phases around the one exchange a sharded job
+// needs: the owner of limb L-1 produces the last limbs in coefficient form (rs_bc), everybody consumes them.
+static int rescale_begin(fhe_ctx *ctx, fhe_keyswitch *p, const uint64_t *d_in, size_t n_parts, hipStream_t st)
 {
-    if (!ctx || !p || !d_in) return fail(FHE_ERR_INVALID, "null argument");
-    if (n_parts < 1 || n_parts > 3) return fail(FHE_ERR_INVALID, "a ciphertext has 1 to 3 parts");
-    for (size_t i = 0; i < n_parts; i++)
-        if (!outs[i]) return fail(FHE_ERR_INVALID, "null argument");
-    if (p->sharded) return fail(FHE_ERR_UNSUPPORTED, "rescale of a limb-sharded ciphertext is not built: gather the last limb on the host side");
-    if (p->L < 2 || !p->last) return fail(FHE_ERR_INVALID, "no prime left to drop");
-    HIP_TRY(hipSetDevice(ctx->device));
-    hipStream_t st = pick(ctx, stream);
+    if (!p->own_last) return FHE_OK;
     const fhe_ntt_tables *t = p->t;
-    const size_t N = (size_t)1 << p->log_n, L = p->L, R = L - 1;
-    const LimbParams *lp = t->d_lp.as<LimbParams>();
-    u64 *last = p->rs_last.as<u64>(), *delta = p->rs_delta.as<u64>();
+    const size_t N = (size_t)1 << p->log_n, cn = p->sh.cn, R = (size_t)p->L - 1, lr = R - p->sh.clo;   // lr: the last limb's row in this rank's slab
     int rc;
-    hipError_t e;
-    TraceScope tr(ctx, st, "RESCALE", true);
-    HIP_TRY(hipMemcpy2DAsync(last, N * 8, d_in + R * N, L * N * 8, N * 8, n_parts, hipMemcpyDeviceToDevice, st));
+    HIP_TRY(hipMemcpy2DAsync(p->rs_bc, N * 8, d_in + lr * N, cn * N * 8, N * 8, n_parts, hipMemcpyDeviceToDevice, st));
     {
         TraceScope tr_ntt(ctx, st, "NTT");
-        PassArgs a{last, lp, (u32)R, 1u, (u32)n_parts, 1u};
-        if ((e = launch_ntt(st, a, p->log_n, true, t->path[R], ctx->geo)) != hipSuccess) return hip_fail(e, "launch_ntt");
+        PassArgs a{p->rs_bc, t->d_lp.as<LimbParams>(), (u32)R, 1u, (u32)n_parts, 1u};
+        hipError_t e = launch_ntt(st, a, p->log_n, true, t->path[R], 1);
+        if (e != hipSuccess) return hip_fail(e, "launch_ntt");
     }
-    if (p->plain_modulus && (rc = fhe_scalar_affine(ctx, last, last, &p->t_inv_qlast, nullptr, t, n_parts, 1, R, st))) return rc;
-    e = launch_baseconv_exact_jobs(st, p->rs_jobs.as<BcJob>(), (u32)n_parts, 1, (int)R, p->last->dev.f64 != 0, N);
+    if (p->plain_modulus && (rc = fhe_scalar_affine(ctx, p->rs_bc, p->rs_bc, &p->t_inv_qlast, nullptr, t, n_parts, 1, R, st))) return rc;
+    return FHE_OK;
+}
+
+static int rescale_finish(fhe_ctx *ctx, fhe_keyswitch *p, uint64_t *const *outs, const uint64_t *d_in, size_t n_parts, hipStream_t st)
+{
+    if (!p->rs_n) return FHE_OK;
+    const fhe_ntt_tables *t = p->t;
+    const size_t N = (size_t)1 << p->log_n, cn = p->sh.cn, R = p->rs_n, lo = p->sh.clo;
+    const LimbParams *lp = t->d_lp.as<LimbParams>();
+    u64 *delta = p->rs_delta.as<u64>();
+    int rc;
+    hipError_t e = launch_baseconv_exact_jobs(st, p->rs_jobs.as<BcJob>(), (u32)n_parts, 1, (int)R, p->last->dev.f64 != 0, N);
     if (e != hipSuccess) return hip_fail(e, "launch_baseconv_exact_jobs");
-    if (p->plain_modulus && (rc = fhe_scalar_affine(ctx, delta, delta, p->t_mod_Q.data(), nullptr, t, n_parts, R, 0, st))) return rc;
+    if (p->plain_modulus && (rc = fhe_scalar_affine(ctx, delta, delta, p->t_mod_Q.data() + lo, nullptr, t, n_parts, R, lo, st))) return rc;
     const bool plain = !ntt_subscale_supported(p->log_n) || ctx->mode != 0 || ctx->fault_idx >= 0 || ctx->packed_on || ctx->only_pass >= 0 || ctx->resident;
     if (plain) {
-        if ((rc = ntt_batch(ctx, delta, t, n_parts, R, 0, st, false))) return rc;
+        if ((rc = ntt_batch(ctx, delta, t, n_parts, R, lo, st, false))) return rc;
         for (size_t part = 0; part < n_parts; part += 2) {
             const bool two = part + 1 < n_parts;
-            const SubScaleArgs sa{outs[part], two ? outs[part + 1] : nullptr, d_in + part * L * N, delta + part * R * N, nullptr,
-                                  p->qlast_inv.as<u64>(), (u64)(L * N), (u64)(R * N), lp, 0u, (u32)R, p->log_n, nullptr};
+            const SubScaleArgs sa{outs[part], two ? outs[part + 1] : nullptr, d_in + part * cn * N, delta + part * R * N, nullptr,
+                                  p->qlast_inv.as<u64>(), (u64)(cn * N), (u64)(R * N), lp, (u32)lo, (u32)R, p->log_n, nullptr};
             if ((e = launch_sub_scale(st, sa)) != hipSuccess) return hip_fail(e, "launch_sub_scale");
         }
         return FHE_OK;
     }
     // forward transform of the residues with (c - delta) / q_last riding on its last pass
     TraceScope tr_ntt(ctx, st, "NTT");
-    return for_each_run(t, R, 0, [&](size_t off, size_t len, int path) -> int {
-        PassArgs a{delta + off * N, lp, (u32)off, (u32)len, (u32)(n_parts * len), (u32)R};
-        RowEpiArgs ep{{nullptr, nullptr, nullptr}, {nullptr, nullptr, nullptr}, d_in + off * N, (u64)(L * N), p->qlast_inv.as<u64>() + off};
+    return for_each_run(t, R, lo, [&](size_t off, size_t len, int path) -> int {
+        PassArgs a{delta + off * N, lp, (u32)(lo + off), (u32)len, (u32)(n_parts * len), (u32)R};
+        RowEpiArgs ep{{nullptr, nullptr, nullptr}, {nullptr, nullptr, nullptr}, d_in + off * N, (u64)(cn * N), p->qlast_inv.as<u64>() + off};
         for (size_t i = 0; i < n_parts; i++) ep.out[i] = outs[i] + off * N;
         hipError_t e2 = launch_ntt_subscale(st, a, ep, p->log_n, path);
         return e2 == hipSuccess ? FHE_OK : hip_fail(e2, "launch_ntt_subscale");
     });
+}
+
+static int rescale_check(fhe_ctx *ctx, fhe_keyswitch *p, const uint64_t *d_in, size_t n_parts)
+{
+    if (!ctx || !p || (!d_in && p->sh.cn)) return fail(FHE_ERR_INVALID, "null argument");
+    if (n_parts < 1 || n_parts > 3) return fail(FHE_ERR_INVALID, "a ciphertext has 1 to 3 parts");
+    if (p->L < 2) return fail(FHE_ERR_INVALID, "no prime left to drop");
+    if (!p->rs_bc) return fail(FHE_ERR_INVALID, "this sharded plan was created without a broadcast buffer for the rescale");
+    return FHE_OK;
+}
+
+static int rescale_core(fhe_ctx *ctx, fhe_keyswitch *p, uint64_t *const *outs, const uint64_t *d_in, size_t n_parts, void *stream)
+{
+    int rc = rescale_check(ctx, p, d_in, n_parts);
+    if (rc) return rc;
+    if (p->sharded) return fail(FHE_ERR_INVALID, "a sharded plan rescales through fhe_rescale_shard_begin / _finish with the broadcast between them");
+    for (size_t i = 0; i < n_parts; i++)
+        if (!outs[i]) return fail(FHE_ERR_INVALID, "null argument");
+    HIP_TRY(hipSetDevice(ctx->device));
+    hipStream_t st = pick(ctx, stream);
+    TraceScope tr(ctx, st, "RESCALE", true);
+    if ((rc = rescale_begin(ctx, p, d_in, n_parts, st))) return rc;
+    return rescale_finish(ctx, p, outs, d_in, n_parts, st);
 }
 
 extern "C" {
@@ -95,12 +120,39 @@ int fhe_rescale(fhe_ctx *ctx, fhe_keyswitch *p, uint64_t *d_out, const uint64_t 
     return rescale_core(ctx, p, outs, d_in, n_parts, stream);
 }
 
+int fhe_rescale_shard_begin(fhe_ctx *ctx, fhe_keyswitch *p, const uint64_t *d_in_local, size_t n_parts, void *stream)
+{
+    int rc = rescale_check(ctx, p, d_in_local, n_parts);
+    if (rc) return rc;
+    HIP_TRY(hipSetDevice(ctx->device));
+    return rescale_begin(ctx, p, d_in_local, n_parts, pick(ctx, stream));
+}
+
+int fhe_rescale_shard_finish(fhe_ctx *ctx, fhe_keyswitch *p, uint64_t *d_out_local, const uint64_t *d_in_local, size_t n_parts, void *stream)
+{
+    int rc = rescale_check(ctx, p, d_in_local, n_parts);
+    if (rc) return rc;
+    if (!d_out_local && p->rs_n) return fail(FHE_ERR_INVALID, "null argument");
+    HIP_TRY(hipSetDevice(ctx->device));
+    const size_t step = (size_t)p->rs_n << p->log_n;
+    uint64_t *outs[3] = {d_out_local, d_out_local + step, d_out_local + 2 * step};
+    return rescale_finish(ctx, p, outs, d_in_local, n_parts, pick(ctx, stream));
+}
+
+int fhe_rescale_shard_info(const fhe_keyswitch *p, int *owns_last, int *out_rows)
+{
+    if (!p) return fail(FHE_ERR_INVALID, "null plan");
+    if (owns_last) *owns_last = p->own_last ? 1 : 0;
+    if (out_rows) *out_rows = p->rs_n;
+    return FHE_OK;
+}
+
 int fhe_hmult(fhe_ctx *ctx, fhe_keyswitch *p, uint64_t *d_out0, uint64_t *d_out1, const uint64_t *d_a0, const uint64_t *d_a1,
               const uint64_t *d_b0, const uint64_t *d_b1, const uint64_t *d_relin_key, int rescale, void *stream)
 {
     if (!ctx || !p || !d_out0 || !d_out1 || !d_relin_key) return fail(FHE_ERR_INVALID, "null argument");
     if (rescale && p->L < 2) return fail(FHE_ERR_INVALID, "no prime left to drop");
-    if (p->sharded) return fail(FHE_ERR_UNSUPPORTED, "fhe_hmult runs on one device; sharded jobs use fhe_tensor_product + the fhe_keyswitch_shard_* phases");
+    if (p->sharded) return fail(FHE_ERR_UNSUPPORTED, "fhe_hmult runs on one device; a sharded job runs fhe_tensor_product, the fhe_keyswitch_shard_* phases and fhe_rescale_shard_* on its rows");
     const size_t N = (size_t)1 << p->log_n, L = p->L;
     u64 *d0 = p->hm.as<u64>(), *d1 = d0 + L * N, *d2 = d1 + L * N, *pre = p->hm_pre.as<u64>();
     int rc;

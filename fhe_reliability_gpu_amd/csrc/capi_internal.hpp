@@ -161,9 +161,12 @@ struct fhe_keyswitch {
     DevBuf ext_map[2];                 // per arithmetic path: the limbs of ext the forward transform covers
     u32 ext_units[2] = {0, 0};
     // homomorphic multiply / rescale on top of the key switch (capi_hmult.cpp); rescale needs L >= 2
-    fhe_baseconv *last = nullptr;      // q_{L-1} -> q_0 .. q_{L-2}
-    DevBuf qlast_inv;                  // q_{L-1}^-1 mod q_j, j < L-1
-    DevBuf rs_last, rs_delta, rs_jobs; // [3][N] last limbs in coefficient form, [3][L-1][N] their residues, job list (3 parts)
+    fhe_baseconv *last = nullptr;      // q_{L-1} -> the owned ciphertext primes below it
+    int rs_n = 0;                      // how many those are (one device: L-1); rescale outputs have rs_n rows per part
+    bool own_last = false;             // this rank owns limb L-1 (it feeds the broadcast)
+    u64 *rs_bc = nullptr;              // [3][N] last limbs in coefficient form: plan-owned on one device, the caller's broadcast buffer when sharded
+    DevBuf qlast_inv;                  // q_{L-1}^-1 mod q_j, owned j < L-1
+    DevBuf rs_last, rs_delta, rs_jobs; // rs_last backs rs_bc on one device; [3][rs_n][N] residues; job list (3 parts)
     DevBuf hm, hm_pre;                 // [3][L][N] tensor product, [2][L][N] relinearised product before the rescale
     u64 t_inv_qlast = 0;               // plain_modulus^-1 mod q_{L-1} (BGV)
     ~fhe_keyswitch()

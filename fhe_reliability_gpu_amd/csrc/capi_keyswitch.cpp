@@ -47,7 +47,7 @@ static u32 g2_row(int L, int K, int world, int k, int h)
 }
 
 static int ks_create(fhe_ctx *ctx, const fhe_ntt_tables *t, int L, int K, int dnum, int world, int rank, uint64_t *d_gather1,
-                     uint64_t *d_gather2, fhe_keyswitch **out)
+                     uint64_t *d_gather2, uint64_t *d_bcast, fhe_keyswitch **out)
 {
     if (!ctx || !t || !out || L < 1 || K < 1 || dnum < 1 || dnum > L || L + K > t->count)
         return fail(FHE_ERR_INVALID, "bad key-switch shape");
@@ -161,23 +161,35 @@ static int ks_create(fhe_ctx *ctx, const fhe_ntt_tables *t, int L, int K, int dn
         HIP_TRY(p->hm.alloc(3 * (size_t)L * N * 8));
         HIP_TRY(p->hm_pre.alloc(2 * (size_t)L * N * 8));
     }
-    if (L >= 2 && !sharded) {
-        // rescale / mod-switch to the next level: drop q_{L-1}
+    if (L >= 2 && (!sharded || d_bcast)) {
+        // rescale / mod-switch to the next level: drop q_{L-1}.  Its owner turns the last limb of every part to coefficient
+        // form; every rank needs it (one device: it is simply there; sharded: ONE broadcast of n_parts x N words into d_bcast)
+        // and forms (c - delta) / q_last on the ciphertext limbs below L-1 that it owns.
         const u64 ql = t->q[L - 1];
-        int rc = fhe_baseconv_create(ctx, &ql, 1, t->q.data(), L - 1, &p->last);
-        if (rc) return rc;
-        std::vector<u64> qinv(L - 1);
-        for (int j = 0; j + 1 < L; j++) {
-            qinv[j] = host::inv_mod(ql % t->q[j], t->q[j]);
-            if (!qinv[j]) return fail(FHE_ERR_INVALID, "ciphertext primes must be pairwise coprime");
+        p->own_last = sh.clo <= L - 1 && L - 1 < sh.clo + sh.cn;
+        p->rs_n = std::max(0, std::min(sh.clo + sh.cn, L - 1) - sh.clo);
+        if (!sharded) {
+            HIP_TRY(p->rs_last.alloc(3 * N * 8));
+            p->rs_bc = p->rs_last.as<u64>();
+        } else {
+            p->rs_bc = d_bcast;
         }
-        HIP_TRY(p->qlast_inv.upload(qinv));
-        HIP_TRY(p->rs_last.alloc(3 * N * 8));
-        HIP_TRY(p->rs_delta.alloc(3 * (size_t)(L - 1) * N * 8));
-        std::vector<BcJob> jobs;
-        for (int part = 0; part < 3; part++)
-            jobs.push_back(BcJob{p->last->dev, p->rs_last.as<u64>() + (size_t)part * N, p->rs_delta.as<u64>() + (size_t)part * (L - 1) * N, 0xFFFFFFFFu, 0u});
-        HIP_TRY(p->rs_jobs.upload(jobs));
+        if (p->rs_n > 0) {
+            int rc = fhe_baseconv_create(ctx, &ql, 1, t->q.data() + sh.clo, p->rs_n, &p->last);
+            if (rc) return rc;
+            std::vector<u64> qinv(p->rs_n);
+            for (int j = 0; j < p->rs_n; j++) {
+                const u64 qj = t->q[sh.clo + j];
+                qinv[j] = host::inv_mod(ql % qj, qj);
+                if (!qinv[j]) return fail(FHE_ERR_INVALID, "ciphertext primes must be pairwise coprime");
+            }
+            HIP_TRY(p->qlast_inv.upload(qinv));
+            HIP_TRY(p->rs_delta.alloc(3 * (size_t)p->rs_n * N * 8));
+            std::vector<BcJob> jobs;
+            for (int part = 0; part < 3; part++)
+                jobs.push_back(BcJob{p->last->dev, p->rs_bc + (size_t)part * N, p->rs_delta.as<u64>() + (size_t)part * p->rs_n * N, 0xFFFFFFFFu, 0u});
+            HIP_TRY(p->rs_jobs.upload(jobs));
+        }
     }
     *out = p.release();
     return FHE_OK;
@@ -355,13 +367,13 @@ int fhe_automorphism_ntt(fhe_ctx *ctx, uint64_t *d_dst, const uint64_t *d_src, i
 
 int fhe_keyswitch_create(fhe_ctx *ctx, const fhe_ntt_tables *t, int L, int K, int dnum, fhe_keyswitch **out)
 {
-    return ks_create(ctx, t, L, K, dnum, 1, 0, nullptr, nullptr, out);
+    return ks_create(ctx, t, L, K, dnum, 1, 0, nullptr, nullptr, nullptr, out);
 }
 
 int fhe_keyswitch_create_sharded(fhe_ctx *ctx, const fhe_ntt_tables *t, int L, int K, int dnum, int world, int rank, uint64_t *d_gather1,
-                                 uint64_t *d_gather2, fhe_keyswitch **out)
+                                 uint64_t *d_gather2, uint64_t *d_bcast, fhe_keyswitch **out)
 {
-    return ks_create(ctx, t, L, K, dnum, world, rank, d_gather1, d_gather2, out);
+    return ks_create(ctx, t, L, K, dnum, world, rank, d_gather1, d_gather2, d_bcast, out);
 }
 
 int fhe_keyswitch_shard_layout(int L, int K, int world, int rank, int out[6])

@@ -158,11 +158,16 @@ class ShardedKeySwitch:
         dev = torch.device("cuda", eng.device)
         self.g1 = torch.zeros((self.world * self.lay["cmax"], n), dtype=torch.int64, device=dev)
         self.g2 = torch.zeros((self.world * 2 * self.lay["smax"], n), dtype=torch.int64, device=dev)
+        self.bc = torch.zeros((3, n), dtype=torch.int64, device=dev)       # last limbs in coefficient form (rescale broadcast)
         h = vp()
         check(lib.fhe_keyswitch_create_sharded(eng._h, tables._h, L, K, dnum, self.world, self.rank, C.c_void_p(self.g1.data_ptr()),
-                                               C.c_void_p(self.g2.data_ptr()), C.byref(h)))
+                                               C.c_void_p(self.g2.data_ptr()), C.c_void_p(self.bc.data_ptr()), C.byref(h)))
         self._h = h
         self.rows1, self.rows2 = self.lay["cmax"], 2 * self.lay["smax"]
+        own, rows = C.c_int(), C.c_int()
+        check(lib.fhe_rescale_shard_info(h, C.byref(own), C.byref(rows)))
+        self.owns_last, self.rs_rows = bool(own.value), rows.value
+        self.last_owner = next(r for r in range(self.world) if (lambda l: l["clo"] <= L - 1 < l["clo"] + l["cn"])(ks_layout(L, K, self.world, r)))
         self._side = None
 
     def stream_scope(self):
@@ -215,6 +220,29 @@ class ShardedKeySwitch:
         out1 = torch.empty_like(out0)
         check(lib.fhe_keyswitch_shard_finish(self.eng._h, self._h, self._p(out0), self._p(out1), self._p(add0), self._p(add1), self._stream()))
         return out0, out1
+
+    def tensor(self, a0, a1, b0, b1):
+        """(d0, d1, d2) of the owned limbs (phantom::multiply, dotprod_test.cu:113): no exchange."""
+        import torch
+
+        from ._lib import check, lib
+        d = [torch.empty_like(a0) for _ in range(3)]
+        if a0.shape[0]:
+            check(lib.fhe_tensor_product(self.eng._h, self._p(d[0]), self._p(d[1]), self._p(d[2]), self._p(a0), self._p(a1), self._p(b0), self._p(b1),
+                                         self.t._h, a0.shape[0], self.lay["clo"], self._stream()))
+        return tuple(d)
+
+    def rescale_begin(self, parts_local):
+        from ._lib import check, lib
+        check(lib.fhe_rescale_shard_begin(self.eng._h, self._h, self._p(parts_local), parts_local.shape[0], self._stream()))
+
+    def rescale_finish(self, parts_local):
+        import torch
+
+        from ._lib import check, lib
+        out = torch.empty((parts_local.shape[0], self.rs_rows, self.t.N), dtype=torch.int64, device=self.g1.device)
+        check(lib.fhe_rescale_shard_finish(self.eng._h, self._h, self._p(out), self._p(parts_local), parts_local.shape[0], self._stream()))
+        return out
 
     def close(self):
         from ._lib import lib
@@ -282,6 +310,62 @@ def sharded_rotate(plan, c0_local, c1_local, galois_elt: int, gk_local, timings=
             check(lib.fhe_automorphism_ntt(plan.eng._h, C.c_void_p(s0.data_ptr()), C.c_void_p(c0_local.data_ptr()), plan.t.log_n, galois_elt, c0_local.shape[0], st))
             check(lib.fhe_automorphism_ntt(plan.eng._h, C.c_void_p(s1.data_ptr()), C.c_void_p(c1_local.data_ptr()), plan.t.log_n, galois_elt, c1_local.shape[0], st))
         return sharded_keyswitch(plan, s1, gk_local, add0=s0, timings=timings)
+
+
+def broadcast_rows(buf, src: int, group=None):
+    """In-place broadcast of ``buf`` from rank ``src`` (CUDA tensors under gloo are staged through host memory)."""
+    import torch.distributed as dist
+
+    world, _ = _group_info(group)
+    if world == 1 and not (dist.is_available() and dist.is_initialized()):
+        return
+    if buf.is_cuda and dist.get_backend(group) == "gloo":
+        host = buf.cpu()
+        dist.broadcast(host, src=src, group=group)
+        buf.copy_(host)
+        return
+    dist.broadcast(buf, src=src, group=group)
+
+
+def sharded_rescale(plan, parts_local, timings=None):
+    """mod_switch_to_next / rescale with the limbs sharded: parts_local = [n_parts, cn, N] (this rank's rows of every part).  The
+    owner of the last ciphertext limb turns it to coefficient form, ONE broadcast of n_parts x N words, then every rank forms
+    (c - delta) / q_last on its rows below the dropped limb.  Returns [n_parts, rows, N].  ``timings``: CUDA events
+    (start, before the broadcast, after it, end) are appended under "rescale_events"."""
+    import contextlib
+    with (plan.stream_scope() if hasattr(plan, "stream_scope") else contextlib.nullcontext()):
+        ev = None
+        if timings is not None:
+            import torch
+            ev = [torch.cuda.Event(enable_timing=True) for _ in range(4)]
+            ev[0].record()
+        plan.rescale_begin(parts_local)
+        if ev:
+            ev[1].record()
+        broadcast_rows(plan.bc, plan.last_owner, plan.group)
+        if ev:
+            ev[2].record()
+        out = plan.rescale_finish(parts_local)
+        if ev:
+            ev[3].record()
+            timings.setdefault("rescale_events", []).append(ev)
+        return out
+
+
+def sharded_hmult(plan, a0, a1, b0, b1, rlk_local, rescale: bool = True, timings=None):
+    """multiply -> relinearize -> mod_switch_to_next (reliability_test/dotprod_test.cu:113-115; BASELINE config 4) on this rank's
+    rows: tensor product (no exchange), the sharded key switch of d2 with d0 / d1 as addends (two all-gathers), the sharded
+    rescale (one broadcast).  Inputs [cn, N] each; returns the two parts' owned rows ([rows, N] each, the last limb dropped)."""
+    import contextlib
+
+    import torch
+    with (plan.stream_scope() if hasattr(plan, "stream_scope") else contextlib.nullcontext()):
+        d0, d1, d2 = plan.tensor(a0, a1, b0, b1)
+        c0, c1 = sharded_keyswitch(plan, d2, rlk_local, add0=d0, add1=d1, timings=timings)
+        if not rescale:
+            return c0, c1
+        r = sharded_rescale(plan, torch.stack([c0, c1]), timings=timings)
+        return r[0], r[1]
 
 
 def own_ct_rows(lay) -> List[int]:

@@ -235,10 +235,11 @@ int fhe_keyswitch_create(fhe_ctx *ctx, const fhe_ntt_tables *t, int L, int K, in
  *                               the owned special limbs of both halves into slot `rank` of d_gather2 ([world][2][smax][N])
  *   -- all-gather of d_gather2 (in place) --
  *   fhe_keyswitch_shard_finish  mod-down to the owned ciphertext limbs (+ optional addends, as a rotation / relinearisation needs)
- * The gather buffers belong to the caller and are fixed at creation.  world = 1 gives fhe_keyswitch_create's plan. */
+ * The gather buffers belong to the caller and are fixed at creation.  world = 1 gives fhe_keyswitch_create's plan.
+ * d_bcast (optional, 3 x N words): broadcast buffer of the sharded rescale below; NULL = the plan does not rescale. */
 int fhe_keyswitch_shard_layout(int L, int K, int world, int rank, int out[6]);
 int fhe_keyswitch_create_sharded(fhe_ctx *ctx, const fhe_ntt_tables *t, int L, int K, int dnum, int world, int rank,
-                                 uint64_t *d_gather1, uint64_t *d_gather2, fhe_keyswitch **out);
+                                 uint64_t *d_gather1, uint64_t *d_gather2, uint64_t *d_bcast, fhe_keyswitch **out);
 int fhe_keyswitch_shard_begin(fhe_ctx *ctx, fhe_keyswitch *p, const uint64_t *d_c_local, void *stream);
 int fhe_keyswitch_shard_inner(fhe_ctx *ctx, fhe_keyswitch *p, const uint64_t *d_c_local, const uint64_t *d_evk_local, void *stream);
 int fhe_keyswitch_shard_finish(fhe_ctx *ctx, fhe_keyswitch *p, uint64_t *d_out0_local, uint64_t *d_out1_local,
@@ -273,6 +274,13 @@ int fhe_relinearize(fhe_ctx *ctx, fhe_keyswitch *p, uint64_t *d_out0, uint64_t *
  * NTT domain.  With a plain modulus set on the plan (BGV) the removed part is t [c t^-1]_{q_last}, so the plaintext is
  * kept up to the factor q_last^-1 mod t. */
 int fhe_rescale(fhe_ctx *ctx, fhe_keyswitch *p, uint64_t *d_out, const uint64_t *d_in, size_t n_parts, void *stream);
+/* fhe_rescale with the limbs sharded (plans of fhe_keyswitch_create_sharded with a d_bcast buffer): d_in_local = [n_parts][cn][N], the
+ * rows this rank owns.  _begin: the owner of limb L-1 (fhe_rescale_shard_info: owns_last) turns the last limb of every part to
+ * coefficient form into d_bcast; the host broadcasts d_bcast from that rank (n_parts x N words, the one exchange); _finish: every
+ * rank forms (c - delta) / q_last on the out_rows owned limbs below L-1, d_out_local = [n_parts][out_rows][N]. */
+int fhe_rescale_shard_info(const fhe_keyswitch *p, int *owns_last, int *out_rows);
+int fhe_rescale_shard_begin(fhe_ctx *ctx, fhe_keyswitch *p, const uint64_t *d_in_local, size_t n_parts, void *stream);
+int fhe_rescale_shard_finish(fhe_ctx *ctx, fhe_keyswitch *p, uint64_t *d_out_local, const uint64_t *d_in_local, size_t n_parts, void *stream);
 /* The three steps above in one call (multiply -> relinearize -> mod_switch, dotprod_test.cu:113-115) on two two-part
  * ciphertexts of L limbs; rescale != 0: outputs have L-1 limbs, else L.  The plan owns the intermediates. */
 int fhe_hmult(fhe_ctx *ctx, fhe_keyswitch *p, uint64_t *d_out0, uint64_t *d_out1, const uint64_t *d_a0, const uint64_t *d_a1,

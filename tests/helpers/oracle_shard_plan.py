@@ -22,6 +22,10 @@ class OracleShardPlan:
         self.g1 = torch.zeros((self.world * self.cmax, self.N), dtype=torch.int64)
         self.g2 = torch.zeros((self.world * 2 * self.smax, self.N), dtype=torch.int64)
         self.rps = np.stack([O.root_powers(q, logn) for q in self.qs])
+        self.bc = torch.zeros((3, self.N), dtype=torch.int64)
+        self.last_owner = next(r for r, l in enumerate(self.lays) if l["clo"] <= L - 1 < l["clo"] + l["cn"])
+        self.owns_last = self.last_owner == self.rank
+        self.rs_rows = max(0, min(self.lay["clo"] + self.lay["cn"], L - 1) - self.lay["clo"])
         lay = self.lay
         self.own = list(range(lay["clo"], lay["clo"] + lay["cn"])) + list(range(lay["slo"], lay["slo"] + lay["sn"]))
 
@@ -95,3 +99,41 @@ class OracleShardPlan:
                     out[j] = self._t(v)
             outs.append(out)
         return outs[0], outs[1]
+
+    # ---- homomorphic multiply on the owned rows (tests of dist.sharded_hmult)
+    def tensor(self, a0, a1, b0, b1):
+        import torch
+        lay = self.lay
+        d = [torch.zeros_like(a0) for _ in range(3)]
+        for j in range(lay["cn"]):
+            q = self.qs[lay["clo"] + j]
+            x0, x1, y0, y1 = (self._np(t[j]) for t in (a0, a1, b0, b1))
+            d[0][j] = self._t(self.O.modmul(x0, y0, q))
+            d[1][j] = self._t(self.O.modmul_acc(self.O.modmul(x0, y1, q), x1, y0, q))
+            d[2][j] = self._t(self.O.modmul(x1, y1, q))
+        return tuple(d)
+
+    def rescale_begin(self, parts_local):
+        if not self.owns_last:
+            return
+        L = self.L
+        row = L - 1 - self.lay["clo"]
+        for p in range(parts_local.shape[0]):
+            self.bc[p] = self._t(self.O.nwt_inverse(self._np(parts_local[p, row]), self.qs[L - 1], self.rps[L - 1]))
+
+    def rescale_finish(self, parts_local):
+        import torch
+        O, lay, N, L = self.O, self.lay, self.N, self.L
+        ql = self.qs[L - 1]
+        out = torch.zeros((parts_local.shape[0], self.rs_rows, N), dtype=torch.int64)
+        for p in range(parts_local.shape[0]):
+            y = self._np(self.bc[p])
+            for j in range(self.rs_rows):
+                tl = lay["clo"] + j
+                q = self.qs[tl]
+                dn = O.nwt_forward(y % np.uint64(q), q, self.rps[tl])
+                c = self._np(parts_local[p, j])
+                diff = (c % np.uint64(q) + (np.uint64(q) - dn)) % np.uint64(q)
+                out[p, j] = self._t(O.modmul(diff, np.full(N, pow(ql % q, -1, q), dtype=np.uint64), q))
+        return out
+

@@ -120,6 +120,49 @@ def test_sharded_keyswitch_gloo(tmp_path, world, L, K, dnum):
         assert got[r].shape[1] == ks_layout(L, K, world, r)["cn"]
 
 
+def _hm_worker(rank, world, port, logn, L, K, dnum, out_dir):
+    import torch
+    import torch.distributed as dist
+
+    from fhe_reliability_gpu_amd.dist import ks_layout, own_ct_rows, own_rows, sharded_hmult
+    from helpers.oracle_shard_plan import OracleShardPlan
+
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        qs, a0, rlk, a1 = _ks_case(logn, L, K, dnum)
+        _, b0, _, b1 = _ks_case(logn, L, K, dnum + 7)
+        b0, b1 = b0 % np.array(qs[:L], dtype=np.uint64)[:, None], b1 % np.array(qs[:L], dtype=np.uint64)[:, None]
+        lay = ks_layout(L, K, world, rank)
+        to_t = lambda a: torch.from_numpy(np.ascontiguousarray(a).view(np.int64).copy())
+        rows = own_ct_rows(lay)
+        plan = OracleShardPlan(qs, logn, L, K, dnum)
+        o0, o1 = sharded_hmult(plan, to_t(a0[rows]), to_t(a1[rows]), to_t(b0[rows]), to_t(b1[rows]), to_t(rlk[:, :, own_rows(lay)]))
+        np.save(os.path.join(out_dir, f"hm{rank}.npy"), np.stack([o0.numpy().view(np.uint64), o1.numpy().view(np.uint64)]))
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("world,L,K,dnum", [(2, 4, 2, 2), (3, 5, 2, 3), (3, 3, 1, 3)])
+def test_sharded_hmult_gloo(tmp_path, world, L, K, dnum):
+    """BASELINE config 4's composite with the limbs sharded: tensor product on the owned rows, the sharded key switch with d0 / d1 as
+    addends, the rescale with ONE broadcast of the last limbs -- concatenated per-rank results equal oracle hmult_ref."""
+    import torch.multiprocessing as mp
+    from oracle.keyswitch_ref import hmult_ref
+
+    logn = 6
+    mp.spawn(_hm_worker, args=(world, _free_port(), logn, L, K, dnum, str(tmp_path)), nprocs=world, join=True)
+    qs, a0, rlk, a1 = _ks_case(logn, L, K, dnum)
+    _, b0, _, b1 = _ks_case(logn, L, K, dnum + 7)
+    qcol = np.array(qs[:L], dtype=np.uint64)[:, None]
+    w0, w1 = hmult_ref(a0, a1, b0 % qcol, b1 % qcol, rlk, qs, L, K, dnum, logn, rescale=True)
+    got = [np.load(tmp_path / f"hm{r}.npy") for r in range(world)]
+    g0 = np.concatenate([g[0] for g in got], axis=0)
+    g1 = np.concatenate([g[1] for g in got], axis=0)
+    assert g0.shape == w0.shape == (L - 1, 1 << logn) and (g0 == w0).all() and (g1 == w1).all()
+
+
 def test_ks_layout_tiles_both_limb_sets():
     """Every ciphertext limb and every special limb has exactly one owner; slab sizes differ by at most one; the total
     per rank (the work per rank) differs by at most one more; cmax / smax are the largest slabs."""

@@ -96,7 +96,14 @@ def _nccl_worker(rank, world, port, out_dir):
         out = sharded_base_conversion(eng, _to_cuda(c[lo:hi]), qs[:L], qs[L:])
         olo, ohi = limb_shard(K, world, rank)
         ok_bc = bool((_from_cuda(out) == O.baseconv_exact(c, qs[:L], qs[L:])[olo:ohi]).all())
-        np.save(os.path.join(out_dir, f"nccl{rank}.npy"), np.array([ok_ks, ok_rot, ok_bc, gather_ms >= 0.0, dist.get_backend() == "nccl"]))
+        # config 4's composite through the same backend: sharded hmult (two all-gathers + one broadcast) = fhe_hmult
+        from fhe_reliability_gpu_amd.dist import sharded_hmult
+        ks1 = F.KeySwitch(eng, t, L, K, dnum)
+        h0, h1 = ks1.hmult(eng.upload(c), eng.upload(add), eng.upload(add), eng.upload(c), eng.upload(evk))
+        s0, s1 = sharded_hmult(plan, _to_cuda(c), _to_cuda(add), _to_cuda(add), _to_cuda(c), _to_cuda(evk))
+        torch.cuda.synchronize()
+        ok_hm = bool((_from_cuda(s0) == h0.download()).all() and (_from_cuda(s1) == h1.download()).all())
+        np.save(os.path.join(out_dir, f"nccl{rank}.npy"), np.array([ok_ks, ok_rot, ok_bc, ok_hm, gather_ms >= 0.0, dist.get_backend() == "nccl"]))
     finally:
         dist.destroy_process_group()
 
@@ -108,7 +115,48 @@ def test_rccl_join_executes_on_one_rank(tmp_path):
     import torch.multiprocessing as mp
     mp.spawn(_nccl_worker, args=(1, _free_port(), str(tmp_path)), nprocs=1, join=True)
     flags = np.load(tmp_path / "nccl0.npy")
-    assert flags.all(), f"(keyswitch, rotate, baseconv, timings, backend) = {flags.tolist()}"
+    assert flags.all(), f"(keyswitch, rotate, baseconv, hmult, timings, backend) = {flags.tolist()}"
+
+
+def _gloo_gpu_hmult_worker(rank, world, port, logn, L, K, dnum, bits, out_dir):
+    import torch
+    import torch.distributed as dist
+
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        import fhe_reliability_gpu_amd as F
+        from fhe_reliability_gpu_amd.dist import ShardedKeySwitch, ks_layout, own_ct_rows, own_rows, sharded_hmult
+        eng = F.Engine(0)
+        qs, a0, rlk, a1 = _case(logn, L, K, dnum, bits)
+        _, b0, _, b1 = _case(logn, L, K, dnum, bits, seed=5)
+        t = eng.tables(logn, qs)
+        lay = ks_layout(L, K, world, rank)
+        rows = own_ct_rows(lay)
+        plan = ShardedKeySwitch(eng, t, L, K, dnum)
+        o0, o1 = sharded_hmult(plan, _to_cuda(a0[rows]), _to_cuda(a1[rows]), _to_cuda(b0[rows]), _to_cuda(b1[rows]), _to_cuda(rlk[:, :, own_rows(lay)]))
+        torch.cuda.synchronize()
+        np.save(os.path.join(out_dir, f"h{rank}.npy"), np.stack([_from_cuda(o0), _from_cuda(o1)]))
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("world,logn,L,K,dnum,bits", [(1, 13, 5, 2, 3, 50), (2, 12, 6, 2, 3, 50), (3, 13, 7, 3, 2, 61), (2, 14, 4, 1, 4, 50)])
+def test_sharded_hmult_real_plan(tmp_path, world, logn, L, K, dnum, bits):
+    """BASELINE config 4's composite with the limbs sharded, on the real C-ABI plan (ranks share cuda:0, joins over gloo): tensor
+    product on the owned rows, sharded relinearisation (d0 / d1 as addends of its last launch), sharded rescale (the last limb's owner
+    broadcasts it) -- concatenated results equal the oracle's hmult_ref, i.e. what fhe_hmult gives on one device."""
+    import torch.multiprocessing as mp
+    from oracle.keyswitch_ref import hmult_ref
+    mp.spawn(_gloo_gpu_hmult_worker, args=(world, _free_port(), logn, L, K, dnum, bits, str(tmp_path)), nprocs=world, join=True)
+    qs, a0, rlk, a1 = _case(logn, L, K, dnum, bits)
+    _, b0, _, b1 = _case(logn, L, K, dnum, bits, seed=5)
+    w0, w1 = hmult_ref(a0, a1, b0, b1, rlk, qs, L, K, dnum, logn, rescale=True)
+    got = [np.load(tmp_path / f"h{r}.npy") for r in range(world)]
+    g0 = np.concatenate([g[0] for g in got], axis=0)
+    g1 = np.concatenate([g[1] for g in got], axis=0)
+    assert g0.shape == w0.shape and (g0 == w0).all() and (g1 == w1).all()
 
 
 def _gloo_gpu_worker(rank, world, port, logn, L, K, dnum, bits, out_dir):
