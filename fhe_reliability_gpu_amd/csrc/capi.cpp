@@ -143,6 +143,26 @@ int ntt_batch(fhe_ctx *ctx, u64 *d, const fhe_ntt_tables *t, size_t n_poly, size
             // a sub-batch's second launch then finds the first one's output on-die (measured on 512 MiB / 2 GiB batches:
             // 0.30 -> 0.32-0.35 of the roofline depending on how many streams run, profiles/r02_chunk_sweep.txt; "ntt_chunk_mib" tunes it).  Limb-major launch order keeps whole limbs together.
             const size_t unit_bytes = N * 8, total = (size_t)a.units * unit_bytes, chunk_bytes = (size_t)ctx->chunk_mib << 20;
+            u64 *pp = nullptr;
+            const bool want_pp = ctx->pingpong < 0 ? total >= ((size_t)64 << 20) : ctx->pingpong != 0;
+            if (want_pp && t->log_n >= 13 && ctx->only_pass < 0 && !a.scratch) {
+                // per-stream hand-off buffer covering one sub-batch (or the whole call) in the data's own layout
+                const bool chunked = chunk_bytes && total > chunk_bytes + (chunk_bytes >> 1) && n_poly > 1;
+                const size_t polys = chunked ? std::max<size_t>(1, chunk_bytes / (unit_bytes * len)) : n_poly;
+                const size_t need = polys * limbs * N * 8;
+                DevBuf *b;
+                {
+                    std::lock_guard<std::mutex> lock(ctx->mu);
+                    auto &slot = ctx->pp_tmp[st];
+                    if (!slot) slot.reset(new DevBuf);
+                    b = slot.get();
+                }
+                if (b->bytes < need) {
+                    HIP_TRY(hipStreamSynchronize(st));
+                    HIP_TRY(b->alloc(need));
+                }
+                pp = b->as<u64>() + off * N;
+            }
             if (chunk_bytes && t->log_n >= 13 && ctx->only_pass < 0 && !a.scratch && total > chunk_bytes + (chunk_bytes >> 1) && n_poly > 1) {
                 const size_t per = std::max<size_t>(1, chunk_bytes / (unit_bytes * len));      // polynomials per sub-batch
                 e = hipSuccess;
@@ -152,9 +172,11 @@ int ntt_batch(fhe_ctx *ctx, u64 *d, const fhe_ntt_tables *t, size_t n_poly, size
                     c.data = a.data + p0 * limbs * N;
                     if (a.src) c.src = a.src + p0 * limbs * N;
                     c.units = (u32)(cnt * len);
+                    c.tmp = pp;
                     e = launch_ntt(st, c, t->log_n, inverse, path, ctx->geo, -1, false);
                 }
             } else {
+                a.tmp = pp;
                 e = launch_ntt(st, a, t->log_n, inverse, path, ctx->geo, ctx->only_pass, ctx->resident);
             }
         }
@@ -246,6 +268,8 @@ int fhe_ctx_create(int device, fhe_ctx **out)
     if (const char *v = getenv("FHE_FUSED_WGS")) c->fused_wgs = (unsigned)std::max(1, atoi(v));
     if (const char *v = getenv("FHE_NTT_RESIDENT")) c->resident = atoi(v) != 0;
     if (const char *v = getenv("FHE_NTT_PACKED")) c->packed_on = atoi(v) != 0;
+    if (const char *v = getenv("FHE_NTT_PINGPONG")) c->pingpong = atoi(v) < 0 ? -1 : atoi(v) ? 1 : 0;
+    if (const char *v = getenv("FHE_NTT_CHUNK_MIB")) c->chunk_mib = (unsigned)std::max(0, atoi(v));
     if (const char *v = getenv("FHE_KS_FUSED")) c->ks_fused = atoi(v) < 0 ? -1 : atoi(v) ? 1 : 0;
     *out = c.release();
     return FHE_OK;
@@ -260,6 +284,7 @@ int fhe_ctx_destroy(fhe_ctx *ctx)
     ctx->garner.clear();
     ctx->fused_ctl.clear();
     ctx->packed.clear();
+    ctx->pp_tmp.clear();
     (void)hipStreamDestroy(ctx->stream);
     delete ctx;
     return FHE_OK;
@@ -275,6 +300,7 @@ int fhe_ctx_set_option(fhe_ctx *ctx, const char *name, long value)
     else if (!std::strcmp(name, "tile_geo")) ctx->geo = value ? 1 : 0;
     else if (!std::strcmp(name, "ntt_resident")) ctx->resident = value != 0;
     else if (!std::strcmp(name, "ntt_packed")) ctx->packed_on = value != 0;
+    else if (!std::strcmp(name, "ntt_pingpong")) ctx->pingpong = value < 0 ? -1 : value ? 1 : 0;
     else if (!std::strcmp(name, "ntt_chunk_mib")) ctx->chunk_mib = (unsigned)std::max(0l, value);
     else if (!std::strcmp(name, "ks_fused")) ctx->ks_fused = value < 0 ? -1 : value ? 1 : 0;
     else if (!std::strcmp(name, "ntt_only_pass")) ctx->only_pass = value == 0 ? 0 : value == 1 ? 1 : -1;   // bench.py times each kernel with it

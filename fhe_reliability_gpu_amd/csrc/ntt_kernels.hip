@@ -200,17 +200,22 @@ static hipError_t launch_transform(hipStream_t st, const PassArgs &a, int which,
             return hipGetLastError();
         }
     }
-    PassArgs second = a;            // only the first launch of a transform reads from a.src
+    PassArgs first = a, second = a;            // only the first launch of a transform reads from a.src
     second.src = nullptr;
+    if (a.tmp && which == -1) {                // ping-pong: data (or src) -> tmp -> data, both launches out of place
+        if (!first.src) first.src = a.data;
+        first.data = a.tmp;
+        second.src = a.tmp;
+    }
     if constexpr (!PS::G::TWO_PASS) {
         if (which == 1) return hipSuccess;
         return launch_pass<typename PS::Single, LOGN, INV, false>(st, a);
     } else if constexpr (!INV) {
-        hipError_t e = which == 1 ? hipSuccess : launch_pass<typename PS::Col, LOGN, INV, true>(st, a);
+        hipError_t e = which == 1 ? hipSuccess : launch_pass<typename PS::Col, LOGN, INV, true>(st, first);
         if (e != hipSuccess || which == 0) return e;
         return launch_pass<typename PS::Row, LOGN, INV, false>(st, second);
     } else {
-        hipError_t e = which == 1 ? hipSuccess : launch_pass<typename PS::Row, LOGN, INV, false>(st, a);
+        hipError_t e = which == 1 ? hipSuccess : launch_pass<typename PS::Row, LOGN, INV, false>(st, first);
         if (e != hipSuccess || which == 0) return e;
         return launch_pass<typename PS::Col, LOGN, INV, true>(st, second);
     }
@@ -967,7 +972,7 @@ size_t ntt_packed_scratch_words() { return (size_t)256 * PK_BLOCK_WORDS; }
 hipError_t launch_ntt(hipStream_t st, const PassArgs &a, int logn, bool inverse, int path, int geo, int which, bool resident)
 {
     if (a.units == 0) return hipSuccess;
-    if (a.src) {               // out-of-place: the plain launches only (no packed hand-off, no resident pass)
+    if (a.src || a.tmp) {      // out-of-place: the plain launches only (no packed hand-off, no resident pass)
         if (a.scratch) return hipErrorInvalidValue;
         geo = 1;
         resident = false;

@@ -95,6 +95,8 @@ struct PassArgs {
     const UnitRef *map = nullptr;     // optional (two-launch path): units[] given explicitly instead of the [poly][limb] grid --
                             // e.g. "every limb of every key-switch digit except the digit's own" in one launch
     u64 *scratch = nullptr; // optional: packed hand-off area, PK_BLOCK_WORDS * 256 words per unit (ntt_core.hpp)
+    u64 *tmp = nullptr;     // optional (two-launch sizes): hand-off buffer of the same layout -- the first launch writes there, the second
+                            // reads it and writes data ("ping-pong": both launches out of place, the result still lands in data)
     const u64 *src = nullptr; // optional: the transform's FIRST launch reads its input from here (same layout as data) -- an
                             // out-of-place transform with no copy; the natural-order transforms (launch_ntt_gs) require it
 };

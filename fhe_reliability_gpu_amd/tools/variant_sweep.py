@@ -39,10 +39,14 @@ def run(nstr, reps=60):
     return max(e0.elapsed_time(e) for e in ee) / reps
 
 
-for packed in (0, 1):
-    for chunk in (0, 64, 128, 256):
-        for nstr in (1, 2):
+modes = (("plain", 0, 0), ("packed", 1, 0), ("pingpong", 0, 1))   # (name, ntt_packed, ntt_pingpong)
+if len(sys.argv) > 2:
+    modes = tuple(m for m in modes if m[0] in sys.argv[2:])
+for name, packed, pingpong in modes:
+    for chunk in (0, 32, 64, 128, 256):
+        for nstr in (1, 2, 4):
             eng.set_option("ntt_packed", packed)
+            eng.set_option("ntt_pingpong", pingpong)
             eng.set_option("ntt_chunk_mib", chunk)
             ms = run(nstr)
-            print(f"polys {polys} packed {packed} chunk_mib {chunk:4d} streams {nstr}: {ms * 1e3:8.1f} us/step  frac {16.0 * N * polys / (ms * 1e-3) / 8e12:.3f}", flush=True)
+            print(f"polys {polys} {name:9s} chunk_mib {chunk:4d} streams {nstr}: {ms * 1e3:8.1f} us/step  frac {16.0 * N * polys / (ms * 1e-3) / 8e12:.3f}", flush=True)
