@@ -62,10 +62,15 @@ static int rescale_finish(fhe_ctx *ctx, fhe_keyswitch *p, uint64_t *const *outs,
     const LimbParams *lp = t->d_lp.as<LimbParams>();
     u64 *delta = p->rs_delta.as<u64>();
     int rc;
-    hipError_t e = launch_baseconv_exact_jobs(st, p->rs_jobs.as<BcJob>(), (u32)n_parts, 1, (int)R, p->last->dev.f64 != 0, N);
-    if (e != hipSuccess) return hip_fail(e, "launch_baseconv_exact_jobs");
-    if (p->plain_modulus && (rc = fhe_scalar_affine(ctx, delta, delta, p->t_mod_Q.data() + lo, nullptr, t, n_parts, R, lo, st))) return rc;
+    hipError_t e;
     const bool plain = !ntt_subscale_supported(p->log_n) || ctx->mode != 0 || ctx->fault_idx >= 0 || ctx->packed_on || ctx->only_pass >= 0 || ctx->resident;
+    // a rescale converts ONE limb: at the two-launch sizes x mod q_j rides on the column pass of the residues' transform
+    const bool trivial = p->log_n >= 13 && !plain;
+    if (!trivial) {
+        e = launch_baseconv_exact_jobs(st, p->rs_jobs.as<BcJob>(), (u32)n_parts, 1, (int)R, p->last->dev.f64 != 0, N);
+        if (e != hipSuccess) return hip_fail(e, "launch_baseconv_exact_jobs");
+        if (p->plain_modulus && (rc = fhe_scalar_affine(ctx, delta, delta, p->t_mod_Q.data() + lo, nullptr, t, n_parts, R, lo, st))) return rc;
+    }
     if (plain) {
         if ((rc = ntt_batch(ctx, delta, t, n_parts, R, lo, st, false))) return rc;
         for (size_t part = 0; part < n_parts; part += 2) {
@@ -82,6 +87,11 @@ static int rescale_finish(fhe_ctx *ctx, fhe_keyswitch *p, uint64_t *const *outs,
         PassArgs a{delta + off * N, lp, (u32)(lo + off), (u32)len, (u32)(n_parts * len), (u32)R};
         RowEpiArgs ep{{nullptr, nullptr, nullptr}, {nullptr, nullptr, nullptr}, d_in + off * N, (u64)(cn * N), p->qlast_inv.as<u64>() + off};
         for (size_t i = 0; i < n_parts; i++) ep.out[i] = outs[i] + off * N;
+        if (trivial) {
+            a.src = p->rs_bc;
+            a.src_bcast = N;
+            if (p->plain_modulus) ep.pre = p->d_t_mod_Q.as<u64>() + lo + off;          // BGV: delta = t * [c t^-1]_{q_last}
+        }
         hipError_t e2 = launch_ntt_subscale(st, a, ep, p->log_n, path);
         return e2 == hipSuccess ? FHE_OK : hip_fail(e2, "launch_ntt_subscale");
     });

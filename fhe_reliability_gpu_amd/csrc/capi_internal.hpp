@@ -150,6 +150,10 @@ struct fhe_keyswitch {
     DevBuf up_rows, down_rows;          // row of each conversion input limb inside g1 / g2 (or acc on one device)
     bool up_f64 = false;
     bool own_path[2] = {false, false};  // arithmetic paths present among the owned limbs
+    bool up_trivial = false;            // one-limb digits (dnum = L, SEAL's form) at a two-launch size: the extension x mod q_j rides on the
+                                        // extended limbs' column pass (UnitRef::src), no conversion launch and no converted copy
+    u32 down_src_row = 0, down_src_stride = 0;   // K = 1: row of the special limb of half 0 in acc / gather buffer 2, rows between the halves
+    DevBuf d_t_mod_Q;                   // plain_modulus mod q_j on the device (BGV factor of the fused tails)
     u32 n_up_jobs = 0;
     std::vector<BcJob> up_host;         // host copy of the digit jobs (mixed arithmetic paths: one launch per digit)
     u64 plain_modulus = 0;              // BGV: delta must vanish modulo this (0 = CKKS-style flooring)

@@ -104,6 +104,7 @@ static int ks_create(fhe_ctx *ctx, const fhe_ntt_tables *t, int L, int K, int dn
         }
         HIP_TRY(p->pinv.upload(pinv));
     }
+    p->up_trivial = p->alpha == 1 && t->log_n >= 13;
     // every owned limb of every digit's extension except the digit's own limbs, one list per arithmetic path
     for (int path = 0; path < 2; path++) {
         std::vector<UnitRef> map;
@@ -111,7 +112,8 @@ static int ks_create(fhe_ctx *ctx, const fhe_ntt_tables *t, int L, int K, int dn
             const int lo = d * p->alpha, hi = std::min(L, lo + p->alpha);
             for (size_t jj = 0; jj < MO; jj++) {
                 const size_t tl = limb_of(jj);
-                if (((int)tl < lo || (int)tl >= hi) && t->path[tl] == path) map.push_back(UnitRef{(u32)(d * MO + jj), (u32)tl});
+                if (((int)tl < lo || (int)tl >= hi) && t->path[tl] == path)
+                    map.push_back(UnitRef{(u32)(d * MO + jj), (u32)tl, p->up_trivial ? up_rows[(size_t)d * p->alpha] : 0xFFFFFFFFu});
             }
         }
         p->ext_units[path] = (u32)map.size();
@@ -135,6 +137,8 @@ static int ks_create(fhe_ctx *ctx, const fhe_ntt_tables *t, int L, int K, int dn
         for (int h = 0; h < 2; h++)
             for (int k = 0; k < K; k++) down_rows[(size_t)h * K + k] = !sharded ? (u32)(h * MO + L + k) : g2_row(L, K, world, k, h);
         HIP_TRY(p->down_rows.upload(down_rows));
+        p->down_src_row = down_rows[0];
+        p->down_src_stride = down_rows[K] - down_rows[0];
         std::vector<BcJob> up, down;
         p->up_batched = true;
         int first = -1;
@@ -226,7 +230,10 @@ static int ks_extend_mac(fhe_ctx *ctx, fhe_keyswitch *p, const uint64_t *d_c, co
     {
         // (one trace line for the phase; the nested NTT line precedes it, as the reference's tools expect of nested costs)
         TraceScope tr_mr(ctx, st, "MODREDUCTION");
-        if (p->up_batched) {
+        const bool trivial = p->up_trivial && ctx->mode == 0;
+        if (trivial) {
+            // one-limb digits: nothing to launch, the column pass below reads the digit's limb and reduces on the load
+        } else if (p->up_batched) {
             e = launch_baseconv_exact_jobs(st, p->up_jobs.as<BcJob>(), p->n_up_jobs, p->up_max_m, p->up_max_k, p->up_f64, N);
             if (e != hipSuccess) return hip_fail(e, "launch_baseconv_exact_jobs");
         } else {
@@ -239,6 +246,7 @@ static int ks_extend_mac(fhe_ctx *ctx, fhe_keyswitch *p, const uint64_t *d_c, co
         for (int path = 0; path < 2; path++) {
             if (!p->ext_units[path] || (fused && p->log_n <= 12)) continue;
             PassArgs a{ext, lp, 0u, 1u, p->ext_units[path], 1u, p->ext_map[path].as<UnitRef>()};
+            if (trivial) a.src = p->g1;
             if ((e = launch_ntt(st, a, p->log_n, false, path, 1, fused ? 0 : -1)) != hipSuccess) return hip_fail(e, "launch_ntt");
         }
     }
@@ -296,10 +304,15 @@ static int ks_finish(fhe_ctx *ctx, fhe_keyswitch *p, uint64_t *d_out0, uint64_t 
     const LimbParams *lp = t->d_lp.as<LimbParams>();
     u64 *acc = p->acc.as<u64>(), *conv = p->conv.as<u64>();
     int rc;
-    hipError_t e = launch_baseconv_exact_jobs(st, p->down_jobs.as<BcJob>(), 2, p->down->dev.m, p->down->dev.k, p->down->dev.f64 != 0, N);
-    if (e != hipSuccess) return hip_fail(e, "launch_baseconv_exact_jobs");
-    if (p->plain_modulus && (rc = fhe_scalar_affine(ctx, conv, conv, p->t_mod_Q.data() + sh.clo, nullptr, t, 2, sh.cn, sh.clo, st))) return rc;
+    hipError_t e;
     const bool plain = !ntt_subscale_supported(p->log_n) || ctx->mode != 0 || ctx->fault_idx >= 0 || ctx->packed_on || ctx->only_pass >= 0 || ctx->resident;
+    // one special prime at a two-launch size: the conversion x mod q_j rides on the converted limbs' column pass
+    const bool trivial = p->K == 1 && p->log_n >= 13 && !plain;
+    if (!trivial) {
+        e = launch_baseconv_exact_jobs(st, p->down_jobs.as<BcJob>(), 2, p->down->dev.m, p->down->dev.k, p->down->dev.f64 != 0, N);
+        if (e != hipSuccess) return hip_fail(e, "launch_baseconv_exact_jobs");
+        if (p->plain_modulus && (rc = fhe_scalar_affine(ctx, conv, conv, p->t_mod_Q.data() + sh.clo, nullptr, t, 2, sh.cn, sh.clo, st))) return rc;
+    }
     if (plain) {
         if ((rc = ntt_batch(ctx, conv, t, 2, sh.cn, sh.clo, st, false))) return rc;
         const SubScaleArgs sa{d_out0, d_out1, acc, conv, d_add0, p->pinv.as<u64>(), (u64)(MO * N), (u64)((size_t)sh.cn * N), lp, (u32)sh.clo, (u32)sh.cn, p->log_n, d_add1};
@@ -311,8 +324,13 @@ static int ks_finish(fhe_ctx *ctx, fhe_keyswitch *p, uint64_t *d_out0, uint64_t 
     TraceScope tr_ntt(ctx, st, "NTT");
     return for_each_run(t, sh.cn, sh.clo, [&](size_t off, size_t len, int path) -> int {
         PassArgs a{conv + off * N, lp, (u32)(sh.clo + off), (u32)len, (u32)(2 * len), (u32)sh.cn};
-        const RowEpiArgs ep{{d_out0 + off * N, d_out1 + off * N, nullptr}, {d_add0 ? d_add0 + off * N : nullptr, d_add1 ? d_add1 + off * N : nullptr, nullptr},
-                            acc + off * N, (u64)(MO * N), p->pinv.as<u64>() + off};
+        RowEpiArgs ep{{d_out0 + off * N, d_out1 + off * N, nullptr}, {d_add0 ? d_add0 + off * N : nullptr, d_add1 ? d_add1 + off * N : nullptr, nullptr},
+                      acc + off * N, (u64)(MO * N), p->pinv.as<u64>() + off};
+        if (trivial) {
+            a.src = (p->sharded ? p->g2 : acc) + (size_t)p->down_src_row * N;
+            a.src_bcast = (u64)p->down_src_stride * N;
+            if (p->plain_modulus) ep.pre = p->d_t_mod_Q.as<u64>() + sh.clo + off;     // BGV: delta = t * [acc t^-1]_P
+        }
         hipError_t e2 = launch_ntt_subscale(st, a, ep, p->log_n, path);
         return e2 == hipSuccess ? FHE_OK : hip_fail(e2, "launch_ntt_subscale");
     });
@@ -403,6 +421,8 @@ int fhe_keyswitch_set_plain_modulus(fhe_keyswitch *p, uint64_t plain_modulus)
             p->t_inv_P.push_back(inv);
         }
         for (int j = 0; j < p->L; j++) p->t_mod_Q.push_back(plain_modulus % p->t->q[j]);
+        (void)hipSetDevice(p->ctx->device);
+        HIP_TRY(p->d_t_mod_Q.upload(p->t_mod_Q));
         if (p->L >= 2) {
             const u64 ql = p->t->q[p->L - 1];
             p->t_inv_qlast = host::inv_mod(plain_modulus % ql, ql);

@@ -10,6 +10,27 @@
 
 namespace fhe {
 
+template <class PASS, bool IS_COL> struct PASS_TCOLS { static constexpr int value = 0; };
+template <class PASS> struct PASS_TCOLS<PASS, true> { static constexpr int value = PASS::TCOLS; };
+
+// where the loading step of a launch reads its tile: nullptr = in place; mirrored layout of a.src; one source limb per polynomial
+// (src_bcast); or the unit list's own source limb
+template <class PASS, int LOGN, bool IS_COL>
+FHE_D const u64 *pass_source(const PassArgs &a, const u64 *base, u32 row0)
+{
+    if (!a.src) return nullptr;
+    const u32 unit = blockIdx.x / PASS::TILES, tile = blockIdx.x % PASS::TILES;
+    const size_t toff = IS_COL ? (size_t)tile * PASS_TCOLS<PASS, IS_COL>::value : (size_t)row0 * PASS::NPTS;
+    if (a.map) {
+        const u32 s = a.map[unit].src;
+        if (s != 0xFFFFFFFFu) return a.src + ((size_t)s << LOGN) + toff;
+    } else if (a.src_bcast) {
+        const u32 polys = a.units / a.limbs;
+        return a.src + (size_t)(unit % polys) * a.src_bcast + toff;
+    }
+    return a.src + (base - a.data);
+}
+
 template <class PASS, int LOGN, bool INV, bool IS_COL>
 __global__ __launch_bounds__(NTT_THREADS) void k_ntt_pass(PassArgs a)
 {
@@ -24,7 +45,7 @@ __global__ __launch_bounds__(NTT_THREADS) void k_ntt_pass(PassArgs a)
     const TwPtr tw = as_global(INV ? p.inv : p.fwd);
     const Tw inv_n = p.inv_n;
     const int tid = threadIdx.x;
-    const u64 *from = a.src ? a.src + (base - a.data) : nullptr;      // out-of-place: this launch loads from the source buffer
+    const u64 *from = pass_source<PASS, LOGN, IS_COL>(a, base, row0);      // out-of-place: this launch loads from the source buffer
     PASS::template phase<0>(tid, base, lds, tw, row0, ctx, inv_n, (NoTap *)nullptr, from);
     if constexpr (PASS::NPHASE > 1) {
         __syncthreads();
@@ -735,12 +756,13 @@ struct SubScaleTap {
     static constexpr bool STORES = true;
     const u64 *acc, *add;       // offset to the tile's first element; add may be null
     u64 *out;
-    u64 scal, q, r0, r1;
+    u64 scal, q, r0, r1, pre;   // pre (0 = none): X is multiplied by it first (the BGV forms' factor t)
     template <class E, class C> FHE_D void in(u32, E, const C &) {}
     template <class C> FHE_D void out_(u32, u64, const C &) {}
     FHE_D u64 one(u64 a, u64 x, const u64 *ad, u32 idx) const
     {
         const u64 av = a < q ? a : barrett128(a, 0, q, r0, r1);
+        if (pre) x = barrett128(x * pre, mulhi64(x, pre), q, r0, r1);
         const u64 d = av >= x ? av - x : av + q - x;
         u64 v = barrett128(d * scal, mulhi64(d, scal), q, r0, r1);
         if (ad) {
@@ -775,8 +797,9 @@ __global__ __launch_bounds__(NTT_THREADS) void k_ntt_row_subscale(PassArgs a, Ro
     const Tw inv_n = p.inv_n;
     const int tid = threadIdx.x;
     const size_t eoff = ((size_t)l << LOGN) + (size_t)row0 * PASS::NPTS;      // element offset inside part h
-    SubScaleTap tap{ep.a + (size_t)h * ep.a_stride + eoff, ep.add[h] ? ep.add[h] + eoff : nullptr, ep.out[h] + eoff, ep.scal[l], p.q, p.barrett_lo, p.barrett_hi};
-    const u64 *from = a.src ? a.src + (base - a.data) : nullptr;
+    SubScaleTap tap{ep.a + (size_t)h * ep.a_stride + eoff, ep.add[h] ? ep.add[h] + eoff : nullptr, ep.out[h] + eoff, ep.scal[l], p.q, p.barrett_lo, p.barrett_hi,
+                    ep.pre ? ep.pre[l] : 0};
+    const u64 *from = pass_source<PASS, LOGN, false>(a, base, row0);
     PASS::template phase<0>(tid, base, lds, tw, row0, ctx, inv_n, &tap, from);
     if constexpr (PASS::NPHASE > 1) {
         __syncthreads();

@@ -27,6 +27,7 @@ struct RowEpiArgs {
     const u64 *a;
     u64 a_stride;
     const u64 *scal;
+    const u64 *pre = nullptr;   // optional per-limb factor applied to the transformed words first (t of the BGV forms)
 };
 bool ntt_subscale_supported(int logn);
 hipError_t launch_ntt_subscale(hipStream_t st, const PassArgs &a, const RowEpiArgs &ep, int logn, int path);

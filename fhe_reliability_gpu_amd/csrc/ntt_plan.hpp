@@ -82,6 +82,8 @@ template <int LOGN, int GEO = 0> struct PlanGeom {
 // which table limb it belongs to.
 struct UnitRef {
     u32 off, limb;
+    u32 src = 0xFFFFFFFFu;  // optional: the unit's FIRST launch reads limb `src` (units of N words from PassArgs::src) instead of its own
+                            // data -- a one-limb base extension (x mod q_limb) riding on the load, no converted copy in memory
 };
 
 // What a pass needs to know about the launch.
@@ -97,6 +99,8 @@ struct PassArgs {
     u64 *scratch = nullptr; // optional: packed hand-off area, PK_BLOCK_WORDS * 256 words per unit (ntt_core.hpp)
     u64 *tmp = nullptr;     // optional (two-launch sizes): hand-off buffer of the same layout -- the first launch writes there, the second
                             // reads it and writes data ("ping-pong": both launches out of place, the result still lands in data)
+    u64 src_bcast = 0;      // with src: every limb of polynomial p reads the ONE source limb at src + p * src_bcast words (its residues modulo
+                            // each limb's prime are taken on the load): the one-limb conversions of a rescale / a K = 1 mod-down
     const u64 *src = nullptr; // optional: the transform's FIRST launch reads its input from here (same layout as data) -- an
                             // out-of-place transform with no copy; the natural-order transforms (launch_ntt_gs) require it
 };

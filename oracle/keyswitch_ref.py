@@ -29,9 +29,11 @@ def _tables(qs, logn):
     return np.stack([O.root_powers(q, logn) for q in qs])
 
 
-def keyswitch_ref(c, evk, qs, L, K, dnum, logn, add0=None, add1=None, rps=None):
+def keyswitch_ref(c, evk, qs, L, K, dnum, logn, add0=None, add1=None, rps=None, plain_modulus=0):
     """c: (L, N) NTT domain; evk: (dnum, 2, L+K, N) NTT domain; returns (out0, out1), each (L, N).
-    add0 / add1: optional (L, N) terms added to the outputs (rotation: sigma(c0); relinearisation: d0, d1)."""
+    add0 / add1: optional (L, N) terms added to the outputs (rotation: sigma(c0); relinearisation: d0, d1).
+    plain_modulus t (BGV form of the mod-down, the scheme of reliability_test/dotprod_test.cu:199-204): the removed part is
+    t * [acc t^-1]_P instead of [acc]_P, so that it vanishes modulo t."""
     M, N = L + K, 1 << logn
     alpha = -(-L // dnum)
     qs = [int(q) for q in qs]
@@ -52,7 +54,12 @@ def keyswitch_ref(c, evk, qs, L, K, dnum, logn, add0=None, add1=None, rps=None):
     P, Q = qs[L:], qs[:L]
     for h in range(2):                                                                         # MODSWITCH
         tP = O.nwt_inverse_batch(acc[h, L:], P, rps[L:])
-        cn = O.nwt_forward_batch(O.baseconv_exact(tP, P, Q), Q, rps[:L])
+        if plain_modulus:
+            tP = np.stack([O.modmul(tP[k], np.full(N, pow(plain_modulus % P[k], -1, P[k]), dtype=np.uint64), P[k]) for k in range(K)])
+        conv = O.baseconv_exact(tP, P, Q)
+        if plain_modulus:
+            conv = np.stack([O.modmul(conv[j], np.full(N, plain_modulus % Q[j], dtype=np.uint64), Q[j]) for j in range(L)])
+        cn = O.nwt_forward_batch(conv, Q, rps[:L])
         out = np.zeros((L, N), dtype=np.uint64)
         add = (add0, add1)[h]
         for j in range(L):

@@ -231,3 +231,25 @@ def test_rotate_is_stream_capture_safe(F, eng):
     graph.replay()
     torch.cuda.synchronize()
     assert bool((o0 == want0).all()) and bool((o1 == want1).all())
+
+
+@pytest.mark.parametrize("logn,L,K,dnum,bits", [(13, 4, 1, 4, 50), (14, 3, 1, 3, 61), (10, 4, 2, 2, 50), (13, 5, 2, 5, 50), (12, 4, 1, 4, 50)])
+def test_keyswitch_bgv_form_and_one_limb_conversions(F, eng, logn, L, K, dnum, bits):
+    """The BGV mod-down (plain modulus set: delta = t [acc t^-1]_P) against the oracle composite, including the shapes whose
+    conversions convert ONE limb (dnum = L and / or K = 1 at the two-launch sizes): there x mod q_j rides on the column pass's
+    load and the factor t on the fused tail, instead of a conversion launch and a scalar pass."""
+    from oracle.keyswitch_ref import keyswitch_ref
+    N, t_plain = 1 << logn, 65537
+    qs = F.create_moduli(N, [bits] * L + [61 if bits == 61 else 50] * K)
+    t = eng.tables(logn, qs)
+    rng = np.random.default_rng(logn * 31 + K)
+    c = np.stack([rng.integers(0, q, N, dtype=np.uint64) for q in qs[:L]])
+    add = np.stack([rng.integers(0, q, N, dtype=np.uint64) for q in qs[:L]])
+    evk = np.stack([np.stack([np.stack([rng.integers(0, q, N, dtype=np.uint64) for q in qs]) for _ in range(2)]) for _ in range(dnum)])
+    ks = F.KeySwitch(eng, t, L, K, dnum)
+    for tp in (0, t_plain):
+        ks.set_plain_modulus(tp)
+        o0, o1 = ks.relinearize(eng.upload(add), eng.upload(c), eng.upload(c), eng.upload(evk))      # key switch of c, + add / + c
+        w0, w1 = keyswitch_ref(c, evk, qs, L, K, dnum, logn, add0=add, add1=c, plain_modulus=tp)
+        assert (o0.download() == w0).all() and (o1.download() == w1).all(), tp
+
