@@ -293,6 +293,9 @@ def main():
 
     extras = not args.no_extras
     also = {}
+    # everything below runs one stream per call: back to the library's default sub-batch size (256 MiB; 64 MiB is the best
+    # size for the two-stream headline loop only, profiles/r02_variant_sweep.txt)
+    eng.set_option("ntt_chunk_mib", 256)
 
     # ------------------------------------------------------------------ secondary measurements (rank 0, one GPU)
     if rank == 0 and extras and world == 1:

@@ -144,10 +144,13 @@ int ntt_batch(fhe_ctx *ctx, u64 *d, const fhe_ntt_tables *t, size_t n_poly, size
             // 0.30 -> 0.32-0.35 of the roofline depending on how many streams run, profiles/r02_chunk_sweep.txt; "ntt_chunk_mib" tunes it).  Limb-major launch order keeps whole limbs together.
             const size_t unit_bytes = N * 8, total = (size_t)a.units * unit_bytes, chunk_bytes = (size_t)ctx->chunk_mib << 20;
             u64 *pp = nullptr;
-            const bool want_pp = ctx->pingpong < 0 ? total >= ((size_t)64 << 20) : ctx->pingpong != 0;
+            // (by default only for calls that are sub-batched, i.e. stream from HBM anyway: for a batch that fits the Infinity Cache
+            // the scratch would double the footprint and push it out)
+            const bool will_chunk = chunk_bytes && total > std::max(chunk_bytes + (chunk_bytes >> 1), (size_t)192 << 20) && n_poly > 1;
+            const bool want_pp = ctx->pingpong < 0 ? will_chunk : ctx->pingpong != 0;
             if (want_pp && t->log_n >= 13 && ctx->only_pass < 0 && !a.scratch) {
                 // per-stream hand-off buffer covering one sub-batch (or the whole call) in the data's own layout
-                const bool chunked = chunk_bytes && total > chunk_bytes + (chunk_bytes >> 1) && n_poly > 1;
+                const bool chunked = chunk_bytes && total > std::max(chunk_bytes + (chunk_bytes >> 1), (size_t)192 << 20) && n_poly > 1;
                 const size_t polys = chunked ? std::max<size_t>(1, chunk_bytes / (unit_bytes * len)) : n_poly;
                 const size_t need = polys * limbs * N * 8;
                 DevBuf *b;
@@ -163,7 +166,8 @@ int ntt_batch(fhe_ctx *ctx, u64 *d, const fhe_ntt_tables *t, size_t n_poly, size
                 }
                 pp = b->as<u64>() + off * N;
             }
-            if (chunk_bytes && t->log_n >= 13 && ctx->only_pass < 0 && !a.scratch && total > chunk_bytes + (chunk_bytes >> 1) && n_poly > 1) {
+            // (only batches that cannot stay in the Infinity Cache as a whole: cutting a 128 MiB batch costs 15 %)
+            if (chunk_bytes && t->log_n >= 13 && ctx->only_pass < 0 && !a.scratch && total > std::max(chunk_bytes + (chunk_bytes >> 1), (size_t)192 << 20) && n_poly > 1) {
                 const size_t per = std::max<size_t>(1, chunk_bytes / (unit_bytes * len));      // polynomials per sub-batch
                 e = hipSuccess;
                 for (size_t p0 = 0; p0 < n_poly && e == hipSuccess; p0 += per) {

@@ -109,7 +109,7 @@ struct fhe_ctx {
     int geo = 1;           // column-tile geometry of the two-launch path (ntt_launch.hpp)
     bool resident = false; // 2^13 / 2^14: one LDS-resident pass instead of two launches (opt-in, see ntt_plan.hpp)
     int pingpong = -1;        // "ntt_pingpong": two-launch transforms hand over through a per-stream scratch buffer (both launches out of
-                              // place: +6 % on batches that stream from HBM, profiles/r02_variant_sweep.txt); -1 = for calls of 64 MiB and more
+                              // place: +6 % on batches that stream from HBM, profiles/r02_variant_sweep.txt); -1 = for calls that are sub-batched
     std::map<hipStream_t, std::unique_ptr<DevBuf>> pp_tmp;
     unsigned chunk_mib = 256; // two-launch transforms of larger batches run as sub-batches of this size (0 = off), capi.cpp ntt_batch
     int ks_fused = -1;     // key-switch inner product fused with the extended limbs' row pass: -1 = by shape, 0 = never, 1 = always (where supported)

@@ -63,8 +63,8 @@ int fhe_ctx_stream(fhe_ctx *ctx, void **stream_out);
  * (fewer bytes, more arithmetic: measured slower, experimental), 0 (default) = 8-byte words in place;
  * "ntt_chunk_mib" sub-batch size of large two-launch transforms (default 256: a sub-batch's second launch finds the first one's
  * output in the 256 MiB Infinity Cache; 0 = one launch pair for the whole batch); "ntt_pingpong" 1 / 0 / -1 = the two launches hand
- * over through a per-stream scratch buffer of one sub-batch, so that both run out of place (always / never / for calls of 64 MiB
- * and more: the default); "ks_fused" -1 / 0 / 1 = key-switch inner product
+ * over through a per-stream scratch buffer of one sub-batch, so that both run out of place (always / never / for calls that are
+ * sub-batched: the default); "ks_fused" -1 / 0 / 1 = key-switch inner product
  * fused with the extended limbs' row pass by shape / never / always;
  * "tile_geo" column-tile geometry of the two-launch path; "ntt_only_pass" 0 / 1 = launch only the
  * first / second pass of a two-pass size (timing of the individual kernels; -1 = whole transform).  Environment overrides at context creation: FHE_NTT_MODE=twopass|fused,
