@@ -696,9 +696,11 @@ __global__ __launch_bounds__(256) void k_automorphism(u64 *dst, const u64 *src, 
     const u32 n = 1u << logn, mask2 = 2 * n - 1;
     for (u64 g = blockIdx.x * (u64)blockDim.x + threadIdx.x; g < total; g += (u64)gridDim.x * blockDim.x) {
         const u32 unit = (u32)(g >> logn), i = (u32)g & (n - 1);
-        const u64 q = lp[limb0 + unit % limbs].q;
+        const LimbParams &p = lp[limb0 + unit % limbs];
+        const u64 q = p.q;
         const u32 j = (u32)(((u64)i * k) & mask2);
-        u64 v = src[g] % q;
+        u64 v = src[g];
+        if (v >= q) v = barrett128(v, 0, q, p.barrett_lo, p.barrett_hi);      // out-of-range words only: no 64-bit division on the hot path
         if (j >= n) v = v ? q - v : 0;
         dst[((u64)unit << logn) + (j & (n - 1))] = v;
     }

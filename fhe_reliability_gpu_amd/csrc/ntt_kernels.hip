@@ -750,6 +750,7 @@ hipError_t launch_polymul(hipStream_t st, const PassArgs &a, u64 *b, u64 *c, int
 // (k_sub_scale's arithmetic, aux_kernels.hip, applied to the words the row pass is about to write: the transformed limbs
 // are never stored and re-read, and the separate launch disappears).  Units: [part h][limb l] of `a.data`.
 // ---------------------------------------------------------------------------
+template <class A>
 struct SubScaleTap {
     static constexpr bool ACTIVE = true;
     static constexpr bool MID = false;
@@ -757,27 +758,51 @@ struct SubScaleTap {
     const u64 *acc, *add;       // offset to the tile's first element; add may be null
     u64 *out;
     u64 scal, q, r0, r1, pre;   // pre (0 = none): X is multiplied by it first (the BGV forms' factor t)
+    double n, ninv;             // ArithF64 limbs: the tail in exact FP64 arithmetic (about 15 operations per word instead of ~80 integer ones)
     template <class E, class C> FHE_D void in(u32, E, const C &) {}
-    template <class C> FHE_D void out_(u32, u64, const C &) {}
-    FHE_D u64 one(u64 a, u64 x, const u64 *ad, u32 idx) const
+    // integer form (ArithU64 limbs; any 64-bit words)
+    FHE_D u64 one_int(u64 a, u64 x, u64 t, bool has_add) const
     {
         const u64 av = a < q ? a : barrett128(a, 0, q, r0, r1);
         if (pre) x = barrett128(x * pre, mulhi64(x, pre), q, r0, r1);
         const u64 d = av >= x ? av - x : av + q - x;
         u64 v = barrett128(d * scal, mulhi64(d, scal), q, r0, r1);
-        if (ad) {
-            const u64 t = ad[idx];
+        if (has_add) {
             v += t < q ? t : barrett128(t, 0, q, r0, r1);
             v = v >= q ? v - q : v;
         }
         return v;
     }
+    // FP64 form: every word canonical (x is the pass's own output; a and t are checked by the caller)
+    FHE_D u64 one_f64(u64 a, u64 x, u64 t, bool has_add) const
+    {
+        const typename ArithF64::Ctx c{n, ninv, q};
+        double xv = ArithF64::from_canonical(x);
+        if (pre) {
+            const double pw = (double)pre;
+            xv = ArithF64::mulmod_w(xv, pw, pw * ninv, c);              // |.| < 0.9 q
+        }
+        const double d = ArithF64::from_canonical(a) - xv;             // |d| < 1.9 q
+        const double sw = (double)scal;
+        double v = ArithF64::mulmod_w(d, sw, sw * ninv, c);            // |v| < 0.9 q
+        if (has_add) v += ArithF64::from_canonical(t);
+        return ArithF64::canonical(v, c);
+    }
     FHE_D void store(u32 idx, u64 x0, u64 x1)
     {
         const ulonglong2 a = *reinterpret_cast<const ulonglong2 *>(acc + idx);
+        ulonglong2 t = ulonglong2{0, 0};
+        if (add) t = *reinterpret_cast<const ulonglong2 *>(add + idx);
         ulonglong2 r;
-        r.x = one(a.x, x0, add, idx);
-        r.y = one(a.y, x1, add, idx + 1);
+        bool fp = A::PATH == PATH_F64;
+        if (A::PATH == PATH_F64) fp = !__builtin_expect((a.x >= q) | (a.y >= q) | (t.x >= q) | (t.y >= q), 0);     // out-of-range words: integer form
+        if (fp) {
+            r.x = one_f64(a.x, x0, t.x, add != nullptr);
+            r.y = one_f64(a.y, x1, t.y, add != nullptr);
+        } else {
+            r.x = one_int(a.x, x0, t.x, add != nullptr);
+            r.y = one_int(a.y, x1, t.y, add != nullptr);
+        }
         *reinterpret_cast<ulonglong2 *>(out + idx) = r;
     }
 };
@@ -797,8 +822,8 @@ __global__ __launch_bounds__(NTT_THREADS) void k_ntt_row_subscale(PassArgs a, Ro
     const Tw inv_n = p.inv_n;
     const int tid = threadIdx.x;
     const size_t eoff = ((size_t)l << LOGN) + (size_t)row0 * PASS::NPTS;      // element offset inside part h
-    SubScaleTap tap{ep.a + (size_t)h * ep.a_stride + eoff, ep.add[h] ? ep.add[h] + eoff : nullptr, ep.out[h] + eoff, ep.scal[l], p.q, p.barrett_lo, p.barrett_hi,
-                    ep.pre ? ep.pre[l] : 0};
+    SubScaleTap<A> tap{ep.a + (size_t)h * ep.a_stride + eoff, ep.add[h] ? ep.add[h] + eoff : nullptr, ep.out[h] + eoff, ep.scal[l], p.q, p.barrett_lo, p.barrett_hi,
+                       ep.pre ? ep.pre[l] : 0, p.n, p.ninv};
     const u64 *from = pass_source<PASS, LOGN, false>(a, base, row0);
     PASS::template phase<0>(tid, base, lds, tw, row0, ctx, inv_n, &tap, from);
     if constexpr (PASS::NPHASE > 1) {
