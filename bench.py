@@ -119,6 +119,8 @@ def main():
     # each library call transforms its slab as sub-batches of this size, so that a sub-batch's second launch finds the first
     # one's output in the 256 MiB Infinity Cache (profiles/r02_variant_sweep.txt: 64 MiB is the best size with two streams)
     eng.set_option("ntt_chunk_mib", args.chunk_mib)
+    # the headline loop feeds --streams streams of its own: the library's own side stream ("ntt_split") stays off there
+    eng.set_option("ntt_split", 0 if args.streams > 1 else -1)
     qs = F.create_moduli(N, [args.bits] * args.limbs)
     tables = eng.tables(LOGN, qs)
     units = args.polys * args.limbs
@@ -274,10 +276,18 @@ def main():
         result["roofline"]["per_launch"] = per_launch
         result["roofline"]["per_launch_note"] = ("whole-batch launches (no sub-batching) inside real transforms on one stream, 200 transforms, an event "
                                                  "between the two launches; each launch moves the batch once in and once out")
-        one_stream_ms = timed_loop(step, 200, 20)
-        result["roofline"]["ms_per_step_one_stream"] = one_stream_ms
+        # ONE library call per step on one caller stream: whole-batch launches, then the library's defaults (sub-batches
+        # alternating between the caller's stream and the context's side stream)
+        eng.set_option("ntt_chunk_mib", 0)
+        one_stream_ms = timed_loop(step, 100, 10)
+        result["roofline"]["ms_per_step_one_call_whole_batch_launches"] = one_stream_ms
+        eng.set_option("ntt_chunk_mib", 64)
+        eng.set_option("ntt_split", -1)
+        one_call_ms = timed_loop(step, 200, 20)
+        result["roofline"]["ms_per_step_one_call_library_defaults"] = one_call_ms
+        result["roofline"]["frac_one_call_library_defaults"] = alg_bytes_per_step / (one_call_ms * 1e-3) / 1e9 / HBM_PEAK_GBS
     else:
-        one_stream_ms = None
+        one_stream_ms = one_call_ms = None
 
     # HBM/fabric bytes per launch pair from the PMC passes committed under profiles/ (rocprofv3 --pmc on this very command
     # line, FETCH_SIZE doubled as MI355X_MICROARCH.md prescribes and as calibrated on this access pattern, plus WRITE_SIZE):
@@ -293,9 +303,9 @@ def main():
 
     extras = not args.no_extras
     also = {}
-    # everything below runs one stream per call: back to the library's default sub-batch size (256 MiB; 64 MiB is the best
-    # size for the two-stream headline loop only, profiles/r02_variant_sweep.txt)
-    eng.set_option("ntt_chunk_mib", 256)
+    # everything below is one library call per step with the library's defaults (64 MiB sub-batches, side stream)
+    eng.set_option("ntt_chunk_mib", 64)
+    eng.set_option("ntt_split", -1)
 
     # ------------------------------------------------------------------ secondary measurements (rank 0, one GPU)
     if rank == 0 and extras and world == 1:
@@ -464,9 +474,11 @@ def main():
             flags = torch.zeros(args.polys * args.limbs, dtype=torch.int32, device="cuda")
             call = lambda: check(lib.fhe_ntt_forward_checked(eng._h, P(data), tables._h, ab._h, args.polys, args.limbs, 0, P(flags), sptr))
             ms = timed_loop(call, 50, 5)
-            base = one_stream_ms if one_stream_ms else timed_loop(step, 50, 5)
+            base = one_call_ms if one_call_ms else timed_loop(step, 50, 5)
             return {"abft_checked_forward_same_batch": {"ms_per_step_device": ms, "unchecked_ms_same_stream": base,
                                                         "overhead_vs_unchecked_same_stream": ms / base - 1.0,
+                                                        "note": "both sides: one library call per step on one caller stream, library defaults "
+                                                                "(64 MiB sub-batches, side stream, ping-pong hand-off)",
                                                         "flags_raised": int(flags.sum().item())}}
         also.update(abft_rate())
 

@@ -75,6 +75,81 @@ int build_tables(fhe_ctx *ctx, int log_n, const u64 *q, int count, const u64 *fw
     return FHE_OK;
 }
 
+// Sub-batch policy of the two-launch transforms ("ntt_chunk_mib"): batches that cannot stay in the 256 MiB Infinity Cache between
+// the two launches are cut into sub-batches that can (only those: cutting a 128 MiB batch costs 15 %).  Returns the polynomials per
+// sub-batch, 0 = one launch pair for the whole batch.
+size_t sub_batch_polys(const fhe_ctx *ctx, int log_n, size_t n_poly, size_t len)
+{
+    const size_t unit_bytes = (size_t)8 << log_n, total = n_poly * len * unit_bytes, chunk_bytes = (size_t)ctx->chunk_mib << 20;
+    if (!chunk_bytes || log_n < 13 || n_poly < 2 || total <= std::max(chunk_bytes + (chunk_bytes >> 1), (size_t)ctx->chunk_floor_mib << 20)) return 0;
+    const size_t per = std::max<size_t>(1, chunk_bytes / (unit_bytes * len));
+    return per < n_poly ? per : 0;
+}
+
+// Per-stream hand-off scratch of the ping-pong transforms ("ntt_pingpong"); *out = null inside a stream capture that would have to
+// allocate (the launches then hand over in place).
+hipError_t handoff_scratch(fhe_ctx *ctx, hipStream_t st, size_t bytes, u64 **out)
+{
+    DevBuf *b;
+    {
+        std::lock_guard<std::mutex> lock(ctx->mu);
+        auto &slot = ctx->pp_tmp[st];
+        if (!slot) slot.reset(new DevBuf);
+        b = slot.get();
+    }
+    *out = nullptr;
+    if (b->bytes < bytes) {
+        hipStreamCaptureStatus cap = hipStreamCaptureStatusNone;
+        (void)hipStreamIsCapturing(st, &cap);
+        if (cap != hipStreamCaptureStatusNone) return hipSuccess;
+        hipError_t e = b->p ? hipStreamSynchronize(st) : hipSuccess;      // growing frees the old block
+        if (e == hipSuccess) e = b->alloc(bytes);
+        if (e != hipSuccess) return e;
+    }
+    *out = b->as<u64>();
+    return hipSuccess;
+}
+
+// fn(stream, first polynomial, count, side scratch) over the sub-batches of a call; with "ntt_split" they alternate between the
+// caller's stream and the context's side stream for it (fork / join by events; side scratch = side_tmp_bytes of the side stream's
+// own, null on the caller's stream), so that one sub-batch's row pass runs under the next one's column pass.
+int for_sub_batches(fhe_ctx *ctx, hipStream_t st, size_t n_poly, size_t per, size_t side_tmp_bytes,
+                    const std::function<hipError_t(hipStream_t, size_t, size_t, u64 *)> &fn)
+{
+    fhe_ctx::Side *sd = nullptr;
+    hipStreamCaptureStatus cap = hipStreamCaptureStatusNone;
+    if (ctx->split && n_poly > per && hipStreamIsCapturing(st, &cap) == hipSuccess && cap == hipStreamCaptureStatusNone) {
+        {
+            std::lock_guard<std::mutex> lock(ctx->mu);
+            auto &slot = ctx->side[st];
+            if (!slot) slot.reset(new fhe_ctx::Side);
+            sd = slot.get();
+        }
+        if (!sd->s) {
+            HIP_TRY(hipStreamCreateWithFlags(&sd->s, hipStreamNonBlocking));
+            HIP_TRY(hipEventCreateWithFlags(&sd->fork, hipEventDisableTiming));
+            HIP_TRY(hipEventCreateWithFlags(&sd->join, hipEventDisableTiming));
+        }
+        if (sd->tmp.bytes < side_tmp_bytes) {
+            HIP_TRY(hipStreamSynchronize(sd->s));
+            HIP_TRY(sd->tmp.alloc(side_tmp_bytes));
+        }
+        HIP_TRY(hipEventRecord(sd->fork, st));
+        HIP_TRY(hipStreamWaitEvent(sd->s, sd->fork, 0));
+    }
+    hipError_t e = hipSuccess;
+    size_t i = 0;
+    for (size_t p0 = 0; p0 < n_poly && e == hipSuccess; p0 += per, ++i) {
+        const bool on_side = sd && (i & 1);
+        e = fn(on_side ? sd->s : st, p0, std::min(per, n_poly - p0), on_side && side_tmp_bytes ? sd->tmp.as<u64>() : nullptr);
+    }
+    if (sd) {   // join even after a failed launch: the side stream must not be left forked
+        HIP_TRY(hipEventRecord(sd->join, sd->s));
+        HIP_TRY(hipStreamWaitEvent(st, sd->join, 0));
+    }
+    return e == hipSuccess ? FHE_OK : hip_fail(e, "sub-batch launch");
+}
+
 // d_src (optional): out-of-place -- the input is read from there (same layout), nothing is copied (PassArgs::src)
 int ntt_batch(fhe_ctx *ctx, u64 *d, const fhe_ntt_tables *t, size_t n_poly, size_t limbs, size_t start_idx, void *stream,
               bool inverse, const u64 *d_src)
@@ -139,46 +214,29 @@ int ntt_batch(fhe_ctx *ctx, u64 *d, const fhe_ntt_tables *t, size_t n_poly, size
                 }
                 a.scratch = sc->as<u64>();
             }
-            // Batches that cannot stay in the 256 MiB Infinity Cache between the two launches are cut into sub-batches that can:
-            // a sub-batch's second launch then finds the first one's output on-die (measured on 512 MiB / 2 GiB batches:
-            // 0.30 -> 0.32-0.35 of the roofline depending on how many streams run, profiles/r02_chunk_sweep.txt; "ntt_chunk_mib" tunes it).  Limb-major launch order keeps whole limbs together.
-            const size_t unit_bytes = N * 8, total = (size_t)a.units * unit_bytes, chunk_bytes = (size_t)ctx->chunk_mib << 20;
+            // Batches that cannot stay in the 256 MiB Infinity Cache between the two launches run as sub-batches that can: a sub-batch's
+            // second launch then finds the first one's output on-die (512 MiB / 2 GiB batches: 0.30 -> 0.34 of the roofline,
+            // profiles/r02_chunk_sweep.txt, r02_split_sweep.txt).  Limb-major launch order keeps whole limbs together.
+            const bool plain = t->log_n >= 13 && ctx->only_pass < 0 && !a.scratch;
+            const size_t per = plain ? sub_batch_polys(ctx, t->log_n, n_poly, len) : 0;
             u64 *pp = nullptr;
-            // (by default only for calls that are sub-batched, i.e. stream from HBM anyway: for a batch that fits the Infinity Cache
-            // the scratch would double the footprint and push it out)
-            const bool will_chunk = chunk_bytes && total > std::max(chunk_bytes + (chunk_bytes >> 1), (size_t)192 << 20) && n_poly > 1;
-            const bool want_pp = ctx->pingpong < 0 ? will_chunk : ctx->pingpong != 0;
-            if (want_pp && t->log_n >= 13 && ctx->only_pass < 0 && !a.scratch) {
-                // per-stream hand-off buffer covering one sub-batch (or the whole call) in the data's own layout
-                const bool chunked = chunk_bytes && total > std::max(chunk_bytes + (chunk_bytes >> 1), (size_t)192 << 20) && n_poly > 1;
-                const size_t polys = chunked ? std::max<size_t>(1, chunk_bytes / (unit_bytes * len)) : n_poly;
-                const size_t need = polys * limbs * N * 8;
-                DevBuf *b;
-                {
-                    std::lock_guard<std::mutex> lock(ctx->mu);
-                    auto &slot = ctx->pp_tmp[st];
-                    if (!slot) slot.reset(new DevBuf);
-                    b = slot.get();
-                }
-                if (b->bytes < need) {
-                    HIP_TRY(hipStreamSynchronize(st));
-                    HIP_TRY(b->alloc(need));
-                }
-                pp = b->as<u64>() + off * N;
+            // hand-off through a per-stream scratch (both launches out of place); by default only for calls that are sub-batched, i.e.
+            // stream from HBM anyway: for a batch that fits the Infinity Cache the scratch would double the footprint and push it out
+            const bool want_pp = ctx->pingpong < 0 ? per != 0 : ctx->pingpong != 0;
+            const size_t pp_bytes = (per ? per : n_poly) * limbs * N * 8;      // one sub-batch (or the whole call) in the data's own layout
+            if (want_pp && plain) {
+                HIP_TRY(handoff_scratch(ctx, st, pp_bytes, &pp));
+                if (pp) pp += off * N;
             }
-            // (only batches that cannot stay in the Infinity Cache as a whole: cutting a 128 MiB batch costs 15 %)
-            if (chunk_bytes && t->log_n >= 13 && ctx->only_pass < 0 && !a.scratch && total > std::max(chunk_bytes + (chunk_bytes >> 1), (size_t)192 << 20) && n_poly > 1) {
-                const size_t per = std::max<size_t>(1, chunk_bytes / (unit_bytes * len));      // polynomials per sub-batch
-                e = hipSuccess;
-                for (size_t p0 = 0; p0 < n_poly && e == hipSuccess; p0 += per) {
+            if (per) {
+                return for_sub_batches(ctx, st, n_poly, per, pp ? pp_bytes : 0, [&](hipStream_t s, size_t p0, size_t cnt, u64 *side_tmp) {
                     PassArgs c = a;
-                    const size_t cnt = std::min(per, n_poly - p0);
                     c.data = a.data + p0 * limbs * N;
                     if (a.src) c.src = a.src + p0 * limbs * N;
                     c.units = (u32)(cnt * len);
-                    c.tmp = pp;
-                    e = launch_ntt(st, c, t->log_n, inverse, path, ctx->geo, -1, false);
-                }
+                    c.tmp = side_tmp ? side_tmp + off * N : pp;
+                    return launch_ntt(s, c, t->log_n, inverse, path, ctx->geo, -1, false);
+                });
             } else {
                 a.tmp = pp;
                 e = launch_ntt(st, a, t->log_n, inverse, path, ctx->geo, ctx->only_pass, ctx->resident);
@@ -273,6 +331,7 @@ int fhe_ctx_create(int device, fhe_ctx **out)
     if (const char *v = getenv("FHE_NTT_RESIDENT")) c->resident = atoi(v) != 0;
     if (const char *v = getenv("FHE_NTT_PACKED")) c->packed_on = atoi(v) != 0;
     if (const char *v = getenv("FHE_NTT_PINGPONG")) c->pingpong = atoi(v) < 0 ? -1 : atoi(v) ? 1 : 0;
+    if (const char *v = getenv("FHE_NTT_SPLIT")) c->split = atoi(v) < 0 ? -1 : atoi(v) ? 1 : 0;
     if (const char *v = getenv("FHE_NTT_CHUNK_MIB")) c->chunk_mib = (unsigned)std::max(0, atoi(v));
     if (const char *v = getenv("FHE_KS_FUSED")) c->ks_fused = atoi(v) < 0 ? -1 : atoi(v) ? 1 : 0;
     *out = c.release();
@@ -289,6 +348,14 @@ int fhe_ctx_destroy(fhe_ctx *ctx)
     ctx->fused_ctl.clear();
     ctx->packed.clear();
     ctx->pp_tmp.clear();
+    for (auto &kv : ctx->side)
+        if (kv.second && kv.second->s) {
+            (void)hipStreamSynchronize(kv.second->s);
+            (void)hipEventDestroy(kv.second->fork);
+            (void)hipEventDestroy(kv.second->join);
+            (void)hipStreamDestroy(kv.second->s);
+        }
+    ctx->side.clear();
     (void)hipStreamDestroy(ctx->stream);
     delete ctx;
     return FHE_OK;
@@ -304,6 +371,8 @@ int fhe_ctx_set_option(fhe_ctx *ctx, const char *name, long value)
     else if (!std::strcmp(name, "tile_geo")) ctx->geo = value ? 1 : 0;
     else if (!std::strcmp(name, "ntt_resident")) ctx->resident = value != 0;
     else if (!std::strcmp(name, "ntt_packed")) ctx->packed_on = value != 0;
+    else if (!std::strcmp(name, "ntt_chunk_floor_mib")) ctx->chunk_floor_mib = (unsigned)std::max(0l, value);
+    else if (!std::strcmp(name, "ntt_split")) ctx->split = value < 0 ? -1 : value ? 1 : 0;
     else if (!std::strcmp(name, "ntt_pingpong")) ctx->pingpong = value < 0 ? -1 : value ? 1 : 0;
     else if (!std::strcmp(name, "ntt_chunk_mib")) ctx->chunk_mib = (unsigned)std::max(0l, value);
     else if (!std::strcmp(name, "ks_fused")) ctx->ks_fused = value < 0 ? -1 : value ? 1 : 0;

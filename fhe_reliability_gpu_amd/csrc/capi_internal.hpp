@@ -10,6 +10,7 @@
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <functional>
 #include <map>
 #include <memory>
 #include <mutex>
@@ -111,7 +112,13 @@ struct fhe_ctx {
     int pingpong = -1;        // "ntt_pingpong": two-launch transforms hand over through a per-stream scratch buffer (both launches out of
                               // place: +6 % on batches that stream from HBM, profiles/r02_variant_sweep.txt); -1 = for calls that are sub-batched
     std::map<hipStream_t, std::unique_ptr<DevBuf>> pp_tmp;
-    unsigned chunk_mib = 256; // two-launch transforms of larger batches run as sub-batches of this size (0 = off), capi.cpp ntt_batch
+    // "ntt_split": sub-batches of one call alternate between the caller's stream and a side stream the context owns (fork / join by
+    // events), so that one sub-batch's row pass overlaps the next one's column pass; -1 = when the call is sub-batched
+    struct Side { hipStream_t s = nullptr; hipEvent_t fork = nullptr, join = nullptr; DevBuf tmp; };
+    std::map<hipStream_t, std::unique_ptr<Side>> side;
+    int split = -1;
+    unsigned chunk_floor_mib = 192;   // batches up to this size (and up to 1.5 sub-batches) are never cut
+    unsigned chunk_mib = 64;  // two-launch transforms of larger batches run as sub-batches of this size (0 = off), capi.cpp ntt_batch
     int ks_fused = -1;     // key-switch inner product fused with the extended limbs' row pass: -1 = by shape, 0 = never, 1 = always (where supported)
     int only_pass = -1;    // measurement hook: 0 / 1 = launch only the first / second pass of a two-pass size
     int fused_variant = 7;   // handoff*2 + stream hint (ntt_launch.hpp); 7 = acquire + nt streaming
@@ -303,6 +310,10 @@ int keyswitch_core(fhe_ctx *ctx, fhe_keyswitch *p, uint64_t *d_out0, uint64_t *d
 int build_tables(fhe_ctx *ctx, int log_n, const fhe::u64 *q, int count, const fhe::u64 *fwd_rows, bool want_inverse, int force_path,
                  const fhe::u64 *psi_or_null, fhe_ntt_tables **out, const fhe::u64 *gs_scale = nullptr);
 int cyclic_tables(fhe_ctx *ctx, int log_n, fhe::u64 mod, fhe::u64 root, int convention, fhe::u64 scale, fhe_ntt_tables **out);
+size_t sub_batch_polys(const fhe_ctx *ctx, int log_n, size_t n_poly, size_t len);
+hipError_t handoff_scratch(fhe_ctx *ctx, hipStream_t st, size_t bytes, fhe::u64 **out);
+int for_sub_batches(fhe_ctx *ctx, hipStream_t st, size_t n_poly, size_t per, size_t side_tmp_bytes,
+                    const std::function<hipError_t(hipStream_t, size_t, size_t, fhe::u64 *)> &fn);
 int ntt_batch(fhe_ctx *ctx, fhe::u64 *d, const fhe_ntt_tables *t, size_t n_poly, size_t limbs, size_t start_idx, void *stream, bool inverse,
               const fhe::u64 *d_src = nullptr);
 int pointwise(fhe_ctx *ctx, fhe::u64 *c, const fhe::u64 *a, const fhe::u64 *b, const fhe_ntt_tables *t, size_t n_poly, size_t limbs,

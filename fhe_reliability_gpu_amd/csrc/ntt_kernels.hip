@@ -446,7 +446,8 @@ __global__ __launch_bounds__(NTT_THREADS) void k_ntt_pass_abft(PassArgs a, AbftA
     ChecksumTap<A, IN, OUT> tap{as_global(ab.win) + ((size_t)limb << LOGN) + pos0, as_global(ab.wout) + ((size_t)limb << LOGN) + pos0,
                                 (const u64 FHE_GLOBAL *)ab.wout8 + ((size_t)limb << LOGN) + pos0, pos0, ab.logp,
                                 typename A::elem(0), typename A::elem(0), 0, 0};
-    PASS::template phase<0>(tid, base, lds, tw, row0, ctx, inv_n, &tap);
+    const u64 *from = pass_source<PASS, LOGN, IS_COL>(a, base, row0);      // ping-pong hand-off: this launch loads from a.src
+    PASS::template phase<0>(tid, base, lds, tw, row0, ctx, inv_n, &tap, from);
     if constexpr (PASS::NPHASE > 1) {
         __syncthreads();
         PASS::template phase<1>(tid, base, lds, tw, row0, ctx, inv_n, &tap);
@@ -473,8 +474,14 @@ static hipError_t launch_checked(hipStream_t st, const PassArgs &a, const AbftAr
         if (which == 1) return hipSuccess;
         hipLaunchKernelGGL((k_ntt_pass_abft<typename PS::Single, LOGN, false, true, true>), dim3(a.units * PS::Single::TILES), dim3(NTT_THREADS), 0, st, a, ab);
     } else {
-        if (which != 1) hipLaunchKernelGGL((k_ntt_pass_abft<typename PS::Col, LOGN, true, true, false>), dim3(a.units * PS::Col::TILES), dim3(NTT_THREADS), 0, st, a, ab);
-        if (which != 0) hipLaunchKernelGGL((k_ntt_pass_abft<typename PS::Row, LOGN, false, false, true>), dim3(a.units * PS::Row::TILES), dim3(NTT_THREADS), 0, st, a, ab);
+        PassArgs first = a, second = a;
+        if (a.tmp && which == -1) {                // ping-pong: data -> tmp -> data, both launches out of place (launch_transform)
+            first.src = a.data;
+            first.data = a.tmp;
+            second.src = a.tmp;
+        }
+        if (which != 1) hipLaunchKernelGGL((k_ntt_pass_abft<typename PS::Col, LOGN, true, true, false>), dim3(a.units * PS::Col::TILES), dim3(NTT_THREADS), 0, st, first, ab);
+        if (which != 0) hipLaunchKernelGGL((k_ntt_pass_abft<typename PS::Row, LOGN, false, false, true>), dim3(a.units * PS::Row::TILES), dim3(NTT_THREADS), 0, st, second, ab);
     }
     return hipGetLastError();
 }
@@ -502,7 +509,8 @@ __global__ __launch_bounds__(NTT_THREADS) void k_ntt_pass_phase(PassArgs a, Phas
     const size_t woff = ((size_t)limb << LOGN) + pos0;
     PhaseTap<A, PASSID> tap{as_global(ph.win) + woff, as_global(ph.umid) + woff, as_global(ph.wout) + woff, (const u64 FHE_GLOBAL *)ph.umid8 + woff,
                             (const u64 FHE_GLOBAL *)ph.wout8 + woff, pos0, ph.logp, typename A::elem(0), typename A::elem(0), 0, 0};
-    PASS::template phase<0>(tid, base, lds, tw, row0, ctx, inv_n, &tap);
+    const u64 *from = pass_source<PASS, LOGN, IS_COL>(a, base, row0);
+    PASS::template phase<0>(tid, base, lds, tw, row0, ctx, inv_n, &tap, from);
     __syncthreads();
     // test hook: a soft error INSIDE this pass -- one bit of one word of the LDS image between two register steps
     if (ph.fault_pass == PASSID && ph.fault_block == blockIdx.x) {
@@ -528,8 +536,14 @@ static hipError_t launch_phases_t(hipStream_t st, const PassArgs &a, const Phase
 {
     typedef Passes<A, LOGN, false, 1> PS;
     if constexpr (PS::G::TWO_PASS) {
-        if (which != 1) hipLaunchKernelGGL((k_ntt_pass_phase<typename PS::Col, LOGN, true, 0>), dim3(a.units * PS::Col::TILES), dim3(NTT_THREADS), 0, st, a, p1);
-        if (which != 0) hipLaunchKernelGGL((k_ntt_pass_phase<typename PS::Row, LOGN, false, 1>), dim3(a.units * PS::Row::TILES), dim3(NTT_THREADS), 0, st, a, p2);
+        PassArgs first = a, second = a;
+        if (a.tmp && which == -1) {                // ping-pong hand-off (launch_transform): the hand-off check then covers the scratch
+            first.src = a.data;
+            first.data = a.tmp;
+            second.src = a.tmp;
+        }
+        if (which != 1) hipLaunchKernelGGL((k_ntt_pass_phase<typename PS::Col, LOGN, true, 0>), dim3(a.units * PS::Col::TILES), dim3(NTT_THREADS), 0, st, first, p1);
+        if (which != 0) hipLaunchKernelGGL((k_ntt_pass_phase<typename PS::Row, LOGN, false, 1>), dim3(a.units * PS::Row::TILES), dim3(NTT_THREADS), 0, st, second, p2);
         return hipGetLastError();
     }
     return hipErrorInvalidValue;

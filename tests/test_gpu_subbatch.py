@@ -1,0 +1,167 @@
+"""Sub-batched two-launch transforms (capi.cpp: sub_batch_polys / for_sub_batches): a call whose batch cannot stay in the Infinity
+Cache runs as sub-batches, alternating between the caller's stream and the context's side stream, handing over through per-stream
+scratch.  Same words as the oracle whatever the cut, the ragged tail, the arithmetic path, the stream split or the hand-off."""
+import ctypes as C
+
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def F():
+    import fhe_reliability_gpu_amd as f
+    return f
+
+
+@pytest.fixture(scope="module")
+def eng(F):
+    return F.default_engine()
+
+
+@pytest.fixture(scope="module")
+def O():
+    from oracle import cport
+    return cport
+
+
+@pytest.fixture
+def small_chunks(eng):
+    """1 MiB sub-batches with no lower bound on the batch size, so that small inputs are cut"""
+    eng.set_option("ntt_chunk_mib", 1)
+    eng.set_option("ntt_chunk_floor_mib", 0)
+    yield
+    eng.sync()
+    eng.check()
+    for k, v in (("ntt_chunk_mib", 64), ("ntt_chunk_floor_mib", 192), ("ntt_split", -1), ("ntt_pingpong", -1)):
+        eng.set_option(k, v)
+
+
+def _oracle_forward(O, data, qs, logn, start=0):
+    rps = np.stack([O.root_powers(q, logn) for q in qs])
+    return np.stack([O.nwt_forward_batch(p, qs, rps) for p in data])
+
+
+@pytest.mark.parametrize("split", [0, 1])
+@pytest.mark.parametrize("pingpong", [-1, 0, 1])
+@pytest.mark.parametrize("logn,bits,n_poly", [(13, [50, 50, 61], 37), (14, [61], 19), (16, [50], 7), (16, [50, 61], 5), (17, [50], 3)])
+def test_cut_batches_match_the_oracle(F, eng, O, small_chunks, logn, bits, n_poly, split, pingpong):
+    N = 1 << logn
+    eng.set_option("ntt_split", split)
+    eng.set_option("ntt_pingpong", pingpong)
+    qs = F.create_moduli(N, bits)
+    t = eng.tables(logn, qs)
+    rng = np.random.default_rng(logn * 7 + n_poly)
+    data = np.stack([np.stack([rng.integers(0, q, N, dtype=np.uint64) for q in qs]) for _ in range(n_poly)])
+    data[n_poly - 1, 0, :] = qs[0] - 1              # extreme values in the ragged last sub-batch
+    d = eng.upload(data)
+    t.forward(d, n_poly=n_poly)
+    got = d.download().reshape(data.shape)
+    assert (got == _oracle_forward(O, data, qs, logn)).all()
+    t.inverse(d, n_poly=n_poly)
+    assert (d.download().reshape(data.shape) == data).all()
+
+
+def test_limb_window_and_repeated_calls_reuse_the_side_stream(F, eng, O, small_chunks):
+    logn, N, n_poly = 13, 1 << 13, 40
+    qs = F.create_moduli(N, [50] * 4)
+    t = eng.tables(logn, qs)
+    rng = np.random.default_rng(3)
+    start, limbs = 1, 2
+    data = np.stack([np.stack([rng.integers(0, q, N, dtype=np.uint64) for q in qs[start:start + limbs]]) for _ in range(n_poly)])
+    want = _oracle_forward(O, data, qs[start:start + limbs], logn)
+    for _ in range(3):                               # the scratch and the fork / join events are reused call after call
+        d = eng.upload(data)
+        t.forward(d, n_poly=n_poly, limbs=limbs, start=start)
+        assert (d.download().reshape(data.shape) == want).all()
+
+
+@pytest.mark.parametrize("pingpong", [-1, 1])
+@pytest.mark.parametrize("logn,bits", [(13, [50, 61]), (16, [50])])
+def test_checked_transforms_cut_the_same_way(F, eng, O, small_chunks, logn, bits, pingpong):
+    """The ABFT transforms (whole-transform and per-phase checks) run as the same sub-batches: clean flags, same output;
+    a corrupted word (the one-shot hooks transform the batch as one launch pair) is still flagged in the right unit."""
+    from fhe_reliability_gpu_amd._lib import check, lib
+    N, n_poly = 1 << logn, 21 if logn == 13 else 5
+    eng.set_option("ntt_pingpong", pingpong)         # 1: the checked launches hand over through the scratch too
+    qs = F.create_moduli(N, bits)
+    t = eng.tables(logn, qs)
+    ab = F.Abft(eng, t)
+    rng = np.random.default_rng(logn)
+    data = np.stack([np.stack([rng.integers(0, q, N, dtype=np.uint64) for q in qs]) for _ in range(n_poly)])
+    want = _oracle_forward(O, data, qs, logn)
+    d = eng.upload(data)
+    flags = ab.forward_checked(d, n_poly=n_poly)
+    assert not flags.any() and (d.download().reshape(data.shape) == want).all()
+    d = eng.upload(data)
+    flags3 = ab.forward_checked_phases(d, n_poly=n_poly)
+    assert not flags3.any() and (d.download().reshape(data.shape) == want).all()
+    unit = n_poly * len(qs) - 2
+    d = eng.upload(data)
+    check(lib.fhe_ctx_inject_fault(eng._h, unit * N + 77, 9))
+    flags = ab.forward_checked(d, n_poly=n_poly)
+    assert flags.tolist() == [1 if u == unit else 0 for u in range(n_poly * len(qs))]
+
+
+def test_capture_keeps_the_sub_batches_on_the_capturing_stream(F, eng, small_chunks):
+    """Inside a stream capture the side stream is not used (no fork out of the capture): the graph replays to the same words."""
+    import torch
+    from fhe_reliability_gpu_amd._lib import check, lib
+    logn, N, n_poly = 13, 1 << 13, 48
+    qs = F.create_moduli(N, [50])
+    t = eng.tables(logn, qs)
+    g = torch.Generator(device="cuda")
+    g.manual_seed(4)
+    src = torch.randint(0, qs[0], (n_poly, N), generator=g, device="cuda", dtype=torch.int64)
+    buf = src.clone()
+
+    def call(s):
+        check(lib.fhe_ntt_forward_batch(eng._h, C.c_void_p(buf.data_ptr()), t._h, n_poly, 1, 0, C.c_void_p(s.cuda_stream)))
+
+    s = torch.cuda.Stream()
+    torch.cuda.synchronize()
+    call(s)
+    torch.cuda.synchronize()
+    want = buf.clone()
+    buf.copy_(src)
+    graph, cap = torch.cuda.CUDAGraph(), torch.cuda.Stream()
+    torch.cuda.synchronize()
+    with torch.cuda.graph(graph, stream=cap):
+        call(cap)
+    buf.copy_(src)
+    torch.cuda.synchronize()
+    graph.replay()
+    torch.cuda.synchronize()
+    assert torch.equal(buf, want)
+
+
+def test_default_policy_on_a_batch_that_streams_from_hbm(F, eng, O):
+    """Library defaults on 208 MiB (416 polynomials of N = 2^16: four sub-batches of 64 MiB, the last one ragged): equal to the
+    same call made as one launch pair, and to the oracle on a polynomial of each sub-batch."""
+    import torch
+    from fhe_reliability_gpu_amd._lib import check, lib
+    logn, N, n_poly = 16, 1 << 16, 416
+    qs = F.create_moduli(N, [50])
+    t = eng.tables(logn, qs)
+    g = torch.Generator(device="cuda")
+    g.manual_seed(8)
+    src = torch.randint(0, qs[0], (n_poly, N), generator=g, device="cuda", dtype=torch.int64)
+    a, b = src.clone(), src.clone()
+    torch.cuda.synchronize()
+    check(lib.fhe_ntt_forward_batch(eng._h, C.c_void_p(a.data_ptr()), t._h, n_poly, 1, 0, None))
+    eng.sync()
+    eng.set_option("ntt_chunk_mib", 0)
+    try:
+        check(lib.fhe_ntt_forward_batch(eng._h, C.c_void_p(b.data_ptr()), t._h, n_poly, 1, 0, None))
+        eng.sync()
+    finally:
+        eng.set_option("ntt_chunk_mib", 64)
+    assert torch.equal(a, b)
+    rp = O.root_powers(qs[0], logn)
+    for p in (0, 127, 128, 300, 415):
+        assert (a[p].cpu().numpy().view(np.uint64) == O.nwt_forward(src[p].cpu().numpy().view(np.uint64), qs[0], rp)).all()
+    check(lib.fhe_ntt_inverse_batch(eng._h, C.c_void_p(a.data_ptr()), t._h, n_poly, 1, 0, None))
+    eng.sync()
+    assert torch.equal(a, src)
+    eng.check()
