@@ -524,7 +524,20 @@ def main():
             gg.manual_seed(7 + rank)
             mk = lambda *shape: torch.randint(0, qk[0], shape, generator=gg, device="cuda", dtype=torch.int64)
             c0, c1, b0, b1, gk = mk(lay["cn"], n), mk(lay["cn"], n), mk(lay["cn"], n), mk(lay["cn"], n), mk(dnum, 2, mo, n)
-            plan = ShardedKeySwitch(eng, tk, L, K, dnum)
+            # every rank finishes its own set-up before the first collective: a rank that failed here must not leave the others
+            # waiting inside an all-gather
+            err = None
+            try:
+                plan = ShardedKeySwitch(eng, tk, L, K, dnum)
+            except Exception as ex:
+                err = ex
+            if world > 1:
+                bad = torch.tensor([1 if err else 0], device="cuda", dtype=torch.int32)
+                dist.all_reduce(bad, op=dist.ReduceOp.MAX)
+                if int(bad.item()) and err is None:
+                    err = RuntimeError("another rank could not build its sharded plan")
+            if err:
+                raise err
             if kind == "rotate":
                 call = lambda tm=None: sharded_rotate(plan, c0, c1, 3, gk, timings=tm)
             else:

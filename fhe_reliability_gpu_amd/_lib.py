@@ -101,6 +101,9 @@ _SIG = {
     "fhe_keyswitch_shard_finish": (ci, [vp, vp, vp, vp, vp, vp, vp]),
     "fhe_keyswitch_apply": (ci, [vp, vp, vp, vp, vp, vp, vp]),
     "fhe_rotate": (ci, [vp, vp, vp, vp, vp, vp, C.c_uint32, vp, vp]),
+    "fhe_rotate_shard_begin": (ci, [vp, vp, vp, C.c_uint32, vp]),
+    "fhe_rotate_shard_inner": (ci, [vp, vp, vp, vp]),
+    "fhe_rotate_shard_finish": (ci, [vp, vp, vp, vp, vp, C.c_uint32, vp]),
     "fhe_tensor_product": (ci, [vp, vp, vp, vp, vp, vp, vp, vp, vp, sz, sz, vp]),
     "fhe_relinearize": (ci, [vp, vp, vp, vp, vp, vp, vp, vp, vp]),
     "fhe_rescale": (ci, [vp, vp, vp, vp, sz, vp]),

@@ -152,9 +152,23 @@ int for_sub_batches(fhe_ctx *ctx, hipStream_t st, size_t n_poly, size_t per, siz
 
 // d_src (optional): out-of-place -- the input is read from there (same layout), nothing is copied (PassArgs::src)
 int ntt_batch(fhe_ctx *ctx, u64 *d, const fhe_ntt_tables *t, size_t n_poly, size_t limbs, size_t start_idx, void *stream,
-              bool inverse, const u64 *d_src)
+              bool inverse, const u64 *d_src, u32 galois, u64 *d_galois_copy)
 {
     if (!ctx || !d) return fail(FHE_ERR_INVALID, "null argument");
+    if (galois) {
+        // the input is sigma_k(d_src) (NTT-domain Galois map): on the load of the inverse transform's first launch where that launch
+        // stages its tile (PassArgs::galois), as a launch of its own otherwise
+        if (!inverse || !d_src || d_src == d || !(galois & 1)) return fail(FHE_ERR_INVALID, "the Galois map rides on an out-of-place inverse transform");
+        if (ctx->mode == 1 || ctx->fault_idx >= 0 || ctx->packed_on || ctx->only_pass >= 0 || ctx->resident || t->log_n < 5) {
+            HIP_TRY(hipSetDevice(ctx->device));
+            u64 *to = d_galois_copy ? d_galois_copy : d;
+            hipError_t e = launch_automorphism_ntt(pick(ctx, stream), to, d_src, (u32)(n_poly * limbs), t->log_n, galois);
+            if (e != hipSuccess) return hip_fail(e, "launch_automorphism_ntt");
+            d_src = d_galois_copy;        // (null: sigma(src) already sits in d, transform in place)
+            galois = 0;
+            d_galois_copy = nullptr;
+        }
+    }
     if (d_src && (ctx->mode == 1 || ctx->fault_idx >= 0 || ctx->packed_on || ctx->only_pass >= 0 || ctx->resident)) {
         // the experimental variants and the test hooks work in place: copy first
         HIP_TRY(hipSetDevice(ctx->device));
@@ -172,6 +186,8 @@ int ntt_batch(fhe_ctx *ctx, u64 *d, const fhe_ntt_tables *t, size_t n_poly, size
     return for_each_run(t, limbs, start_idx, [&](size_t off, size_t len, int path) -> int {
         PassArgs a{d + off * N, t->d_lp.as<LimbParams>(), (u32)(start_idx + off), (u32)len, (u32)(n_poly * len), (u32)limbs};
         if (d_src) a.src = d_src + off * N;
+        a.galois = galois;
+        if (d_galois_copy) a.galois_copy = d_galois_copy + off * N;
         hipError_t e;
         if (ctx->mode == 1 && fused_supported(t->log_n)) {
             DevBuf *ctl;

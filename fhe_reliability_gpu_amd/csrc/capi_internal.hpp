@@ -315,7 +315,7 @@ hipError_t handoff_scratch(fhe_ctx *ctx, hipStream_t st, size_t bytes, fhe::u64 
 int for_sub_batches(fhe_ctx *ctx, hipStream_t st, size_t n_poly, size_t per, size_t side_tmp_bytes,
                     const std::function<hipError_t(hipStream_t, size_t, size_t, fhe::u64 *)> &fn);
 int ntt_batch(fhe_ctx *ctx, fhe::u64 *d, const fhe_ntt_tables *t, size_t n_poly, size_t limbs, size_t start_idx, void *stream, bool inverse,
-              const fhe::u64 *d_src = nullptr);
+              const fhe::u64 *d_src = nullptr, fhe::u32 galois = 0, fhe::u64 *d_galois_copy = nullptr);
 int pointwise(fhe_ctx *ctx, fhe::u64 *c, const fhe::u64 *a, const fhe::u64 *b, const fhe_ntt_tables *t, size_t n_poly, size_t limbs,
               size_t start_idx, void *stream, bool acc);
 

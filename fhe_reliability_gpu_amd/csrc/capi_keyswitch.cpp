@@ -202,13 +202,14 @@ static int ks_create(fhe_ctx *ctx, const fhe_ntt_tables *t, int L, int K, int dn
 // ---------------------------------------------------------------- the phases
 // INTT of the owned ciphertext limbs (the "3 INTT" that open KEYSWITCH in the L = 4 trace, 16384_4:468-470) into this
 // rank's slot of gather buffer 1
-static int ks_begin(fhe_ctx *ctx, fhe_keyswitch *p, const uint64_t *d_c, hipStream_t st)
+// galois != 0 (a rotation): the input is sigma_k(d_c), taken on the INTT's load; d_sig receives sigma_k(d_c) itself for the inner product
+static int ks_begin(fhe_ctx *ctx, fhe_keyswitch *p, const uint64_t *d_c, hipStream_t st, u32 galois = 0, u64 *d_sig = nullptr)
 {
     const KsShard &sh = p->sh;
     if (!sh.cn) return FHE_OK;
     const size_t N = (size_t)1 << p->log_n;
     u64 *slot = p->g1 + (size_t)sh.rank * sh.cmax * N;
-    return ntt_batch(ctx, slot, p->t, 1, sh.cn, sh.clo, st, true, d_c);     // out of place: the input is the caller's, no copy
+    return ntt_batch(ctx, slot, p->t, 1, sh.cn, sh.clo, st, true, d_c, galois, d_sig);     // out of place: the input is the caller's, no copy
 }
 
 // base extension of each digit to every other owned prime (MODREDUCTION, 16384_4:471-452), their transforms, and the inner
@@ -293,9 +294,17 @@ static int ks_special_intt(fhe_ctx *ctx, fhe_keyswitch *p, hipStream_t st)
     return FHE_OK;
 }
 
+// the mod-down's tail rides on the last pass of the converted limbs' forward transform (ks_finish) unless a test hook or an
+// experimental transform variant is active
+static bool ks_fast_path(const fhe_ctx *ctx, const fhe_keyswitch *p)
+{
+    return ntt_subscale_supported(p->log_n) && ctx->mode == 0 && ctx->fault_idx < 0 && !ctx->packed_on && ctx->only_pass < 0 && !ctx->resident;
+}
+
 // rest of the mod-down, to the owned ciphertext limbs: conversion of the (gathered) special limbs to Q, NTT, subtract, times P^-1
+// (galois != 0: the addends are sigma_k(d_add*), read through the Galois map by the fused tail -- ks_fast_path() shapes only)
 static int ks_finish(fhe_ctx *ctx, fhe_keyswitch *p, uint64_t *d_out0, uint64_t *d_out1, const uint64_t *d_add0, const uint64_t *d_add1,
-                     hipStream_t st)
+                     hipStream_t st, u32 galois = 0)
 {
     const fhe_ntt_tables *t = p->t;
     const KsShard &sh = p->sh;
@@ -305,7 +314,8 @@ static int ks_finish(fhe_ctx *ctx, fhe_keyswitch *p, uint64_t *d_out0, uint64_t 
     u64 *acc = p->acc.as<u64>(), *conv = p->conv.as<u64>();
     int rc;
     hipError_t e;
-    const bool plain = !ntt_subscale_supported(p->log_n) || ctx->mode != 0 || ctx->fault_idx >= 0 || ctx->packed_on || ctx->only_pass >= 0 || ctx->resident;
+    const bool plain = !ks_fast_path(ctx, p);
+    if (plain && galois) return fail(FHE_ERR_INVALID, "the Galois map on the addends belongs to the fused tail");
     // one special prime at a two-launch size: the conversion x mod q_j rides on the converted limbs' column pass
     const bool trivial = p->K == 1 && p->log_n >= 13 && !plain;
     if (!trivial) {
@@ -326,6 +336,7 @@ static int ks_finish(fhe_ctx *ctx, fhe_keyswitch *p, uint64_t *d_out0, uint64_t 
         PassArgs a{conv + off * N, lp, (u32)(sh.clo + off), (u32)len, (u32)(2 * len), (u32)sh.cn};
         RowEpiArgs ep{{d_out0 + off * N, d_out1 + off * N, nullptr}, {d_add0 ? d_add0 + off * N : nullptr, d_add1 ? d_add1 + off * N : nullptr, nullptr},
                       acc + off * N, (u64)(MO * N), p->pinv.as<u64>() + off};
+        ep.galois = galois;
         if (trivial) {
             a.src = (p->sharded ? p->g2 : acc) + (size_t)p->down_src_row * N;
             a.src_bcast = (u64)p->down_src_stride * N;
@@ -471,22 +482,67 @@ int fhe_keyswitch_shard_finish(fhe_ctx *ctx, fhe_keyswitch *p, uint64_t *d_out0_
     return ks_finish(ctx, p, d_out0_local, d_out1_local, d_add0_local, d_add1_local, pick(ctx, stream));
 }
 
+// the last phase of a rotation: the mod-down with sigma(c0) added to the first part -- through the Galois map on the fused tail's
+// load, or (test hooks, experimental transform variants, N < 2^5) from a permuted copy made by a launch of its own
+static int rotate_finish(fhe_ctx *ctx, fhe_keyswitch *p, uint64_t *d_out0, uint64_t *d_out1, const uint64_t *d_c0, u32 galois, hipStream_t st)
+{
+    if (ks_fast_path(ctx, p) || !p->sh.cn) return ks_finish(ctx, p, d_out0, d_out1, d_c0, nullptr, st, galois);
+    const size_t N = (size_t)1 << p->log_n;
+    u64 *sig0 = p->rot.as<u64>() + (size_t)p->sh.cn * N;
+    hipError_t e = launch_automorphism_ntt(st, sig0, d_c0, (u32)p->sh.cn, p->log_n, galois);
+    if (e != hipSuccess) return hip_fail(e, "launch_automorphism_ntt");
+    return ks_finish(ctx, p, d_out0, d_out1, sig0, nullptr, st);
+}
+
 int fhe_rotate(fhe_ctx *ctx, fhe_keyswitch *p, uint64_t *d_out0, uint64_t *d_out1, const uint64_t *d_c0, const uint64_t *d_c1,
                uint32_t galois_elt, const uint64_t *d_galois_key, void *stream)
 {
     if (!ctx || !p || !d_out0 || !d_out1 || !d_c0 || !d_c1 || !d_galois_key) return fail(FHE_ERR_INVALID, "null argument");
     if (d_out0 == d_c0 || d_out1 == d_c1) return fail(FHE_ERR_INVALID, "rotate is out of place");
+    if (!(galois_elt & 1)) return fail(FHE_ERR_INVALID, "Galois elements are odd");
+    if (p->sharded)
+        return fail(FHE_ERR_INVALID, "a sharded plan runs through fhe_rotate_shard_begin / _inner / _finish with the all-gathers between them");
     HIP_TRY(hipSetDevice(ctx->device));
     hipStream_t st = pick(ctx, stream);
     TraceScope tr(ctx, st, "ROTATE", true);
-    const size_t L = p->L, N = (size_t)1 << p->log_n;
-    u64 *sig0 = p->rot.as<u64>(), *sig1 = sig0 + L * N;
-    // sigma on both parts (in the NTT domain a permutation of the slots), one launch
-    hipError_t e = launch_automorphism_ntt(st, sig0, d_c0, (u32)L, p->log_n, galois_elt, sig1, d_c1);
-    if (e != hipSuccess) return hip_fail(e, "launch_automorphism_ntt");
-    // sigma(c1) is a ciphertext part under sigma(s): switch it back to s with the Galois key; the mod-down's last
-    // launch adds sigma(c0) to the first part and writes both parts where the caller wants them
-    return keyswitch_core(ctx, p, d_out0, d_out1, sig1, d_galois_key, sig0, nullptr, st);
+    // sigma(c1) is a ciphertext part under sigma(s): switch it back to s with the Galois key; sigma(c0) is added to the first part.
+    // Both automorphisms (in the NTT domain: permutations of the slots) ride on loads of the key switch's own launches: the opening
+    // INTT reads c1 through the map (and leaves sigma(c1) in the plan's buffer for the inner product), the mod-down's tail reads c0
+    // through it.
+    int rc;
+    TraceScope tr_ks(ctx, st, "KEYSWITCH");
+    u64 *sig1 = p->rot.as<u64>();
+    if ((rc = ks_begin(ctx, p, d_c1, st, galois_elt, sig1))) return rc;
+    if ((rc = ks_extend_mac(ctx, p, sig1, d_galois_key, st))) return rc;
+    TraceScope tr_ms(ctx, st, "MODSWITCH");
+    if ((rc = ks_special_intt(ctx, p, st))) return rc;
+    return rotate_finish(ctx, p, d_out0, d_out1, d_c0, galois_elt, st);
+}
+
+// The three phases of a rotation on a limb-sharded plan (the joins between them are the key switch's, fhe_keyswitch_shard_*): the
+// automorphism permutes slots inside each limb, so every rank applies it to its own rows -- on the loads of its launches.
+int fhe_rotate_shard_begin(fhe_ctx *ctx, fhe_keyswitch *p, const uint64_t *d_c1_local, uint32_t galois_elt, void *stream)
+{
+    if (!ctx || !p || (!d_c1_local && p->sh.cn) || !(galois_elt & 1)) return fail(FHE_ERR_INVALID, "bad rotation arguments");
+    HIP_TRY(hipSetDevice(ctx->device));
+    return ks_begin(ctx, p, d_c1_local, pick(ctx, stream), galois_elt, p->rot.as<u64>());
+}
+
+int fhe_rotate_shard_inner(fhe_ctx *ctx, fhe_keyswitch *p, const uint64_t *d_galois_key_local, void *stream)
+{
+    if (!ctx || !p || !d_galois_key_local) return fail(FHE_ERR_INVALID, "null argument");
+    HIP_TRY(hipSetDevice(ctx->device));
+    hipStream_t st = pick(ctx, stream);
+    int rc = ks_extend_mac(ctx, p, p->rot.as<u64>(), d_galois_key_local, st);
+    return rc ? rc : ks_special_intt(ctx, p, st);
+}
+
+int fhe_rotate_shard_finish(fhe_ctx *ctx, fhe_keyswitch *p, uint64_t *d_out0_local, uint64_t *d_out1_local, const uint64_t *d_c0_local,
+                            uint32_t galois_elt, void *stream)
+{
+    if (!ctx || !p || ((!d_out0_local || !d_out1_local || !d_c0_local) && p->sh.cn) || !(galois_elt & 1)) return fail(FHE_ERR_INVALID, "bad rotation arguments");
+    HIP_TRY(hipSetDevice(ctx->device));
+    return rotate_finish(ctx, p, d_out0_local, d_out1_local, d_c0_local, galois_elt, pick(ctx, stream));
 }
 
 } // extern "C"

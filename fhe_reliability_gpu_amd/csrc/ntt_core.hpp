@@ -342,6 +342,17 @@ struct ColPass {
 // conflict free.  The stride-1 step is the LAST one of a forward pass and the FIRST
 // one of an inverse pass; on that side the tile goes HBM <-> LDS in a separate,
 // fully coalesced copy phase (16 bytes per lane, lanes contiguous).
+// NTT-domain Galois map x -> x^k on a limb in the transform's bit-reversed slot order: slot j evaluates at psi^(2 bitrev(j) + 1)
+// and (sigma_k f)(x) = f(x^k), so sigma_k(f)[j] = f[j'] with 2 bitrev(j') + 1 = (2 bitrev(j) + 1) k mod 2N (the index map behind
+// phantom::rotate_inplace, reliability_test/dotprod_test.cu:146).  An aligned block of 64 slots maps onto an aligned block of 64
+// slots, so a wavefront that reads 64 adjacent slots through the map touches one 512-byte segment.
+FHE_HD u32 galois_slot(u32 j, int logn, u32 k)
+{
+    const u32 e = 2 * brev_bits(j, logn) + 1;
+    const u32 e2 = (u32)(((u64)e * k) & ((2ull << logn) - 1ull));
+    return brev_bits((e2 - 1) >> 1, logn);
+}
+
 // ---------------------------------------------------------------------------
 FHE_HD constexpr u32 row_pad(u32 g) { return g + ((g >> 4) << 1); }
 
@@ -411,6 +422,17 @@ struct RowPass {
             dst[1] = __builtin_bit_cast(elem, v1);
         }
     }
+    // the same tile read through the Galois map: LDS image of sigma_k(src) (src_limb = the source limb's first word); one word per
+    // lane, so a wavefront reads one 512-byte segment; `copy` (optional) receives the mapped tile as is
+    static FHE_D void copy_in_galois(int tid, const u64 *__restrict__ src_limb, u32 row0, elem *__restrict__ lds, u32 k, u64 *__restrict__ copy)
+    {
+        for (int i = tid; i < TR * NPTS; i += NTHREADS) {
+            const u32 row = (u32)i / NPTS, g = (u32)i % NPTS;
+            const u64 v = src_limb[galois_slot((row0 + row) * NPTS + g, LOGN, k)];
+            lds[row * ROW_LDS + row_pad(g)] = __builtin_bit_cast(elem, v);
+            if (copy) copy[i] = v;
+        }
+    }
     // coalesced copy LDS -> HBM (forward; the image already holds final 64-bit words)
     template <class TAP = NoTap>
     static FHE_D void copy_out(int tid, u64 *__restrict__ base, const elem *__restrict__ lds, const typename A::Ctx &c, TAP *tap = nullptr)
@@ -444,10 +466,12 @@ struct RowPass {
     // `src` (optional, ROWMODE 0): the loading step reads the tile from there instead of `base` -- out-of-place first launch.
     template <int E, class TAP = NoTap>
     static FHE_D void phase(int tid, u64 *__restrict__ base, elem *__restrict__ lds, TwPtr tw, u32 row0,
-                            const typename A::Ctx &c, const Tw &inv_n, TAP *tap = nullptr, const u64 *src = nullptr)
+                            const typename A::Ctx &c, const Tw &inv_n, TAP *tap = nullptr, const u64 *src = nullptr, u32 galois = 0,
+                            u64 *galois_copy = nullptr)
     {
         if constexpr (STAGE_IN && E == 0) {
             if constexpr (ROWMODE == 1) gather_in(tid, src, row0, lds);
+            else if (galois && src) copy_in_galois(tid, src - (size_t)row0 * NPTS, row0, lds, galois, galois_copy);
             else copy_in(tid, src ? src : base, lds);
         } else if constexpr (STAGE_OUT && E == NPHASE - 1) {
             copy_out<TAP>(tid, base, lds, c, tap);

@@ -46,7 +46,11 @@ __global__ __launch_bounds__(NTT_THREADS) void k_ntt_pass(PassArgs a)
     const Tw inv_n = p.inv_n;
     const int tid = threadIdx.x;
     const u64 *from = pass_source<PASS, LOGN, IS_COL>(a, base, row0);      // out-of-place: this launch loads from the source buffer
-    PASS::template phase<0>(tid, base, lds, tw, row0, ctx, inv_n, (NoTap *)nullptr, from);
+    if constexpr (!IS_COL && INV) {   // (a rotation's automorphism on the opening INTT's load, PassArgs::galois)
+        PASS::template phase<0>(tid, base, lds, tw, row0, ctx, inv_n, (NoTap *)nullptr, from, a.galois, a.galois_copy ? a.galois_copy + (base - a.data) : nullptr);
+    } else {
+        PASS::template phase<0>(tid, base, lds, tw, row0, ctx, inv_n, (NoTap *)nullptr, from);
+    }
     if constexpr (PASS::NPHASE > 1) {
         __syncthreads();
         PASS::template phase<1>(tid, base, lds, tw, row0, ctx, inv_n);
@@ -223,6 +227,8 @@ static hipError_t launch_transform(hipStream_t st, const PassArgs &a, int which,
     }
     PassArgs first = a, second = a;            // only the first launch of a transform reads from a.src
     second.src = nullptr;
+    second.galois = 0;
+    second.galois_copy = nullptr;
     if (a.tmp && which == -1) {                // ping-pong: data (or src) -> tmp -> data, both launches out of place
         if (!first.src) first.src = a.data;
         first.data = a.tmp;
@@ -773,6 +779,9 @@ struct SubScaleTap {
     u64 *out;
     u64 scal, q, r0, r1, pre;   // pre (0 = none): X is multiplied by it first (the BGV forms' factor t)
     double n, ninv;             // ArithF64 limbs: the tail in exact FP64 arithmetic (about 15 operations per word instead of ~80 integer ones)
+    const u64 *add_limb;        // galois != 0: the addend is sigma_k(add) -- read through the Galois map from the limb's first word
+    u32 pos0, galois;           // (index of the tile's first word inside its limb; a rotation's sigma(c0), RowEpiArgs::galois)
+    int logn;
     template <class E, class C> FHE_D void in(u32, E, const C &) {}
     // integer form (ArithU64 limbs; any 64-bit words)
     FHE_D u64 one_int(u64 a, u64 x, u64 t, bool has_add) const
@@ -806,7 +815,10 @@ struct SubScaleTap {
     {
         const ulonglong2 a = *reinterpret_cast<const ulonglong2 *>(acc + idx);
         ulonglong2 t = ulonglong2{0, 0};
-        if (add) t = *reinterpret_cast<const ulonglong2 *>(add + idx);
+        if (add) {
+            if (galois) t = ulonglong2{add_limb[galois_slot(pos0 + idx, logn, galois)], add_limb[galois_slot(pos0 + idx + 1, logn, galois)]};
+            else t = *reinterpret_cast<const ulonglong2 *>(add + idx);
+        }
         ulonglong2 r;
         bool fp = A::PATH == PATH_F64;
         if (A::PATH == PATH_F64) fp = !__builtin_expect((a.x >= q) | (a.y >= q) | (t.x >= q) | (t.y >= q), 0);     // out-of-range words: integer form
@@ -837,7 +849,7 @@ __global__ __launch_bounds__(NTT_THREADS) void k_ntt_row_subscale(PassArgs a, Ro
     const int tid = threadIdx.x;
     const size_t eoff = ((size_t)l << LOGN) + (size_t)row0 * PASS::NPTS;      // element offset inside part h
     SubScaleTap<A> tap{ep.a + (size_t)h * ep.a_stride + eoff, ep.add[h] ? ep.add[h] + eoff : nullptr, ep.out[h] + eoff, ep.scal[l], p.q, p.barrett_lo, p.barrett_hi,
-                       ep.pre ? ep.pre[l] : 0, p.n, p.ninv};
+                       ep.pre ? ep.pre[l] : 0, p.n, p.ninv, ep.add[h] ? ep.add[h] + ((size_t)l << LOGN) : nullptr, row0 * (u32)PASS::NPTS, ep.galois, LOGN};
     const u64 *from = pass_source<PASS, LOGN, false>(a, base, row0);
     PASS::template phase<0>(tid, base, lds, tw, row0, ctx, inv_n, &tap, from);
     if constexpr (PASS::NPHASE > 1) {

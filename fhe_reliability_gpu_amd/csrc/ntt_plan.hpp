@@ -103,6 +103,10 @@ struct PassArgs {
                             // each limb's prime are taken on the load): the one-limb conversions of a rescale / a K = 1 mod-down
     const u64 *src = nullptr; // optional: the transform's FIRST launch reads its input from here (same layout as data) -- an
                             // out-of-place transform with no copy; the natural-order transforms (launch_ntt_gs) require it
+    u32 galois = 0;         // with src, inverse transforms whose first launch stages its tile (N >= 2^5): the input is sigma_k(src) -- the
+                            // NTT-domain Galois map applied on the load (galois_slot, ntt_core.hpp) -- instead of src: a rotation's
+                            // automorphism rides on the opening INTT of its key switch
+    u64 *galois_copy = nullptr; // optional: sigma_k(src) itself is also written there (same layout; the key switch's inner product reads it)
 };
 
 template <class A, int LOGN, bool INVERSE, int GEO = 0>

@@ -221,6 +221,25 @@ class ShardedKeySwitch:
         check(lib.fhe_keyswitch_shard_finish(self.eng._h, self._h, self._p(out0), self._p(out1), self._p(add0), self._p(add1), self._stream()))
         return out0, out1
 
+    # the three phases of a rotation: the automorphism rides on loads of the key switch's own launches (fhe_rotate_shard_*)
+    def rotate_begin(self, c1_local, galois_elt: int):
+        from ._lib import check, lib
+        check(lib.fhe_rotate_shard_begin(self.eng._h, self._h, self._p(c1_local), galois_elt, self._stream()))
+
+    def rotate_inner(self, gk_local):
+        from ._lib import check, lib
+        check(lib.fhe_rotate_shard_inner(self.eng._h, self._h, self._p(gk_local), self._stream()))
+
+    def rotate_finish(self, c0_local, galois_elt: int):
+        import torch
+
+        from ._lib import check, lib
+        cn = self.lay["cn"]
+        out0 = torch.empty((cn, self.t.N), dtype=torch.int64, device=self.g1.device)
+        out1 = torch.empty_like(out0)
+        check(lib.fhe_rotate_shard_finish(self.eng._h, self._h, self._p(out0), self._p(out1), self._p(c0_local), galois_elt, self._stream()))
+        return out0, out1
+
     def tensor(self, a0, a1, b0, b1):
         """(d0, d1, d2) of the owned limbs (phantom::multiply, dotprod_test.cu:113): no exchange."""
         import torch
@@ -270,25 +289,32 @@ def sharded_keyswitch(plan, c_local, evk_local, add0=None, add1=None, timings=No
         return _sharded_keyswitch(plan, c_local, evk_local, add0, add1, timings)
 
 
-def _sharded_keyswitch(plan, c_local, evk_local, add0, add1, timings):
+def _sharded_keyswitch(plan, c_local, evk_local, add0, add1, timings, galois=0):
+    """galois != 0: a rotation -- c_local is c1, add0 is c0, both un-permuted; the plan applies sigma on its loads"""
     ev = None
     if timings is not None:
         import torch
         ev = [torch.cuda.Event(enable_timing=True) for _ in range(6)]
         ev[0].record()
-    plan.begin(c_local)
+    if galois:
+        plan.rotate_begin(c_local, galois)
+    else:
+        plan.begin(c_local)
     if ev:
         ev[1].record()
     all_gather_slots(plan.g1, plan.rows1, plan.group)
     if ev:
         ev[2].record()
-    plan.inner(c_local, evk_local)
+    if galois:
+        plan.rotate_inner(evk_local)
+    else:
+        plan.inner(c_local, evk_local)
     if ev:
         ev[3].record()
     all_gather_slots(plan.g2, plan.rows2, plan.group)
     if ev:
         ev[4].record()
-    out = plan.finish(add0, add1)
+    out = plan.rotate_finish(add0, galois) if galois else plan.finish(add0, add1)
     if ev:
         ev[5].record()
         timings.setdefault("events", []).append(ev)
@@ -296,20 +322,10 @@ def _sharded_keyswitch(plan, c_local, evk_local, add0, add1, timings):
 
 
 def sharded_rotate(plan, c0_local, c1_local, galois_elt: int, gk_local, timings=None):
-    """ROTATE with limbs sharded: the automorphism permutes slots inside each limb (no exchange), then the key switch of
-    sigma(c1) with sigma(c0) added to the first part."""
-    import ctypes as C
-
-    import torch
-
-    from ._lib import check, lib
+    """ROTATE with limbs sharded: the automorphism permutes slots inside each limb (no exchange) and rides on the loads of the key
+    switch's own launches: the key switch of sigma(c1) with sigma(c0) added to the first part, same two joins."""
     with plan.stream_scope():
-        s0, s1 = torch.empty_like(c0_local), torch.empty_like(c1_local)
-        st = C.c_void_p(torch.cuda.current_stream().cuda_stream)
-        if c0_local.shape[0]:
-            check(lib.fhe_automorphism_ntt(plan.eng._h, C.c_void_p(s0.data_ptr()), C.c_void_p(c0_local.data_ptr()), plan.t.log_n, galois_elt, c0_local.shape[0], st))
-            check(lib.fhe_automorphism_ntt(plan.eng._h, C.c_void_p(s1.data_ptr()), C.c_void_p(c1_local.data_ptr()), plan.t.log_n, galois_elt, c1_local.shape[0], st))
-        return sharded_keyswitch(plan, s1, gk_local, add0=s0, timings=timings)
+        return _sharded_keyswitch(plan, c1_local, gk_local, c0_local, None, timings, galois=galois_elt)
 
 
 def broadcast_rows(buf, src: int, group=None):

@@ -1,5 +1,5 @@
 """Runs fhe_keyswitch_apply in a loop (random NTT-form inputs) so that rocprofv3 can break a key switch down
-by kernel:  rocprofv3 --kernel-trace --stats -d out -- python3 fhe_reliability_gpu_amd/tools/ks_loop.py 16 16 4 4 20"""
+by kernel:  rocprofv3 --kernel-trace --stats -d out -- python3 fhe_reliability_gpu_amd/tools/ks_loop.py 16 16 4 4 20 [rotate]"""
 import os
 import sys
 
@@ -9,6 +9,7 @@ sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspa
 import fhe_reliability_gpu_amd as F  # noqa: E402
 
 logn, L, K, dnum, reps = (int(x) for x in sys.argv[1:6])
+rotate = len(sys.argv) > 6 and sys.argv[6] == "rotate"
 n = 1 << logn
 eng = F.Engine(0)
 qs = F.create_moduli(n, [50] * (L + K))
@@ -17,6 +18,10 @@ ks = F.KeySwitch(eng, t, L, K, dnum)
 rng = np.random.default_rng(1)
 rand = lambda shape: eng.upload(rng.integers(0, qs[0], size=shape, dtype=np.uint64))
 c, evk = rand((L, n)), rand((dnum, 2, L + K, n))
+c0 = rand((L, n))
 for _ in range(reps):
-    ks.apply(c, evk)
+    if rotate:
+        ks.rotate(c0, c, 3, evk)
+    else:
+        ks.apply(c, evk)
 eng.sync()

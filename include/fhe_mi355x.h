@@ -262,6 +262,17 @@ int fhe_keyswitch_apply(fhe_ctx *ctx, fhe_keyswitch *p, uint64_t *d_out0, uint64
  * out0 + out1*s ~ sigma(c0 + c1*s). */
 int fhe_rotate(fhe_ctx *ctx, fhe_keyswitch *p, uint64_t *d_out0, uint64_t *d_out1, const uint64_t *d_c0, const uint64_t *d_c1,
                uint32_t galois_elt, const uint64_t *d_galois_key, void *stream);
+/* The same rotation on a limb-sharded plan (fhe_keyswitch_create_sharded): the automorphism permutes slots inside a limb, so each
+ * rank applies it to its own rows -- on the loads of the launches below, there is no permuted copy of c0 and no launch for it.
+ * Phases and joins as for the sharded key switch:
+ *   fhe_rotate_shard_begin   INTT of sigma(c1)'s owned limbs into this rank's rows of d_gather1   -- all-gather of d_gather1 --
+ *   fhe_rotate_shard_inner   extension, NTT, inner product with the owned Galois-key rows, INTT of the owned special limbs
+ *                            -- all-gather of d_gather2 --
+ *   fhe_rotate_shard_finish  mod-down to the owned limbs, sigma(c0) added to the first part */
+int fhe_rotate_shard_begin(fhe_ctx *ctx, fhe_keyswitch *p, const uint64_t *d_c1_local, uint32_t galois_elt, void *stream);
+int fhe_rotate_shard_inner(fhe_ctx *ctx, fhe_keyswitch *p, const uint64_t *d_galois_key_local, void *stream);
+int fhe_rotate_shard_finish(fhe_ctx *ctx, fhe_keyswitch *p, uint64_t *d_out0_local, uint64_t *d_out1_local, const uint64_t *d_c0_local,
+                            uint32_t galois_elt, void *stream);
 /* ---- homomorphic multiply: tensor product, relinearisation, rescale (BASELINE config 4) -------------- */
 /* phantom::multiply (reliability_test/dotprod_test.cu:113; frontend MULTIPLY_CKKS of the SEAL traces,
  * profile_framewk/build/data/ckks/16384_4:388-389): per limb d0 = a0 b0, d1 = a0 b1 + a1 b0, d2 = a1 b1 on NTT-form

@@ -253,3 +253,35 @@ def test_keyswitch_bgv_form_and_one_limb_conversions(F, eng, logn, L, K, dnum, b
         w0, w1 = keyswitch_ref(c, evk, qs, L, K, dnum, logn, add0=add, add1=c, plain_modulus=tp)
         assert (o0.download() == w0).all() and (o1.download() == w1).all(), tp
 
+
+
+@pytest.mark.parametrize("logn,L,K,dnum,bits", [(4, 2, 1, 2, 50), (5, 3, 1, 3, 50), (8, 3, 2, 2, 61), (12, 4, 1, 2, 50), (13, 4, 1, 4, 50),
+                                                (14, 5, 2, 3, 61), (16, 3, 1, 3, 50)])
+def test_rotate_with_the_automorphism_on_the_loads(F, eng, logn, L, K, dnum, bits):
+    """fhe_rotate applies sigma_k on the loads of the key switch's own launches (the opening INTT reads c1 through the NTT-domain
+    Galois map, the mod-down's tail reads c0 through it): every word equals the oracle composite -- automorphism as a pass of
+    its own, then the key switch -- for several Galois elements, on both arithmetic paths, at single-launch and two-launch sizes,
+    and in the settings that take the separate-launch route (N < 2^5, experimental transform variants)."""
+    from oracle.keyswitch_ref import rotate_ref
+    N = 1 << logn
+    qs = F.create_moduli(N, [bits] * L + [61 if bits == 61 else 50] * K)
+    t = eng.tables(logn, qs)
+    rng = np.random.default_rng(logn * 13 + L)
+    c0 = np.stack([rng.integers(0, q, N, dtype=np.uint64) for q in qs[:L]])
+    c1 = np.stack([rng.integers(0, q, N, dtype=np.uint64) for q in qs[:L]])
+    gk = np.stack([np.stack([np.stack([rng.integers(0, q, N, dtype=np.uint64) for q in qs]) for _ in range(2)]) for _ in range(dnum)])
+    ks = F.KeySwitch(eng, t, L, K, dnum)
+    d0, d1, dk = eng.upload(c0), eng.upload(c1), eng.upload(gk)
+    for k in (3, 2 * N - 1, 5 if logn < 6 else (1 << (logn - 1)) + 1):
+        w0, w1 = rotate_ref(c0, c1, k, gk, qs, L, K, dnum, logn)
+        o0, o1 = ks.rotate(d0, d1, k, dk)
+        assert (o0.download() == w0).all() and (o1.download() == w1).all(), f"galois element {k}"
+        assert (d0.download() == c0).all() and (d1.download() == c1).all()          # inputs untouched
+        if 13 <= logn <= 14:
+            eng.set_option("ntt_resident", 1)
+            try:
+                r0, r1 = ks.rotate(d0, d1, k, dk)
+            finally:
+                eng.set_option("ntt_resident", 0)
+            assert (r0.download() == w0).all() and (r1.download() == w1).all(), f"galois element {k}, separate-launch route"
+    eng.check()
