@@ -76,8 +76,21 @@ int build_tables(fhe_ctx *ctx, int log_n, const u64 *q, int count, const u64 *fw
 }
 
 // Sub-batch policy of the two-launch transforms ("ntt_chunk_mib"): batches that cannot stay in the 256 MiB Infinity Cache between
-// the two launches are cut into sub-batches that can (only those: cutting a 128 MiB batch costs 15 %).  Returns the polynomials per
-// sub-batch, 0 = one launch pair for the whole batch.
+// the two launches are cut into sub-batches that can (only those: cutting a 128 MiB batch costs 15 %).  A piece is `pc` polynomials
+// x `lc` limbs of the run: as many polynomials of as few limbs as fit, so that a piece works with few twiddle tables (a table is
+// fetched once per piece and XCD: 16 limbs x 8 polynomials per piece cost 0.27 of the roofline where 2 limbs x 64 cost 0.30).
+// pc = 0: one launch pair for the whole batch.
+SubBatchCut sub_batch_cut(const fhe_ctx *ctx, int log_n, size_t n_poly, size_t len)
+{
+    const size_t unit_bytes = (size_t)8 << log_n, total = n_poly * len * unit_bytes, chunk_bytes = (size_t)ctx->chunk_mib << 20;
+    if (!chunk_bytes || log_n < 13 || n_poly * len < 2 || total <= std::max(chunk_bytes + (chunk_bytes >> 1), (size_t)ctx->chunk_floor_mib << 20))
+        return SubBatchCut{0, 0};
+    const size_t pc = std::min(n_poly, std::max<size_t>(1, chunk_bytes / unit_bytes));
+    const size_t lc = std::min(len, std::max<size_t>(1, chunk_bytes / (unit_bytes * pc)));
+    if (pc == n_poly && lc == len) return SubBatchCut{0, 0};
+    return SubBatchCut{pc, lc};
+}
+// the same policy for callers that cut along the polynomials only (whole limbs of the run in every piece)
 size_t sub_batch_polys(const fhe_ctx *ctx, int log_n, size_t n_poly, size_t len)
 {
     const size_t unit_bytes = (size_t)8 << log_n, total = n_poly * len * unit_bytes, chunk_bytes = (size_t)ctx->chunk_mib << 20;
@@ -110,15 +123,14 @@ hipError_t handoff_scratch(fhe_ctx *ctx, hipStream_t st, size_t bytes, u64 **out
     return hipSuccess;
 }
 
-// fn(stream, first polynomial, count, side scratch) over the sub-batches of a call; with "ntt_split" they alternate between the
-// caller's stream and the context's side stream for it (fork / join by events; side scratch = side_tmp_bytes of the side stream's
-// own, null on the caller's stream), so that one sub-batch's row pass runs under the next one's column pass.
-int for_sub_batches(fhe_ctx *ctx, hipStream_t st, size_t n_poly, size_t per, size_t side_tmp_bytes,
-                    const std::function<hipError_t(hipStream_t, size_t, size_t, u64 *)> &fn)
+// fn(stream, piece, side scratch) over the pieces of a call; with "ntt_split" they alternate between the caller's stream and the
+// context's side stream for it (fork / join by events; side scratch = side_tmp_bytes of the side stream's own, null on the caller's
+// stream), so that one piece's row pass runs under the next one's column pass.
+int for_pieces(fhe_ctx *ctx, hipStream_t st, size_t n_pieces, size_t side_tmp_bytes, const std::function<hipError_t(hipStream_t, size_t, u64 *)> &fn)
 {
     fhe_ctx::Side *sd = nullptr;
     hipStreamCaptureStatus cap = hipStreamCaptureStatusNone;
-    if (ctx->split && n_poly > per && hipStreamIsCapturing(st, &cap) == hipSuccess && cap == hipStreamCaptureStatusNone) {
+    if (ctx->split && n_pieces > 1 && hipStreamIsCapturing(st, &cap) == hipSuccess && cap == hipStreamCaptureStatusNone) {
         {
             std::lock_guard<std::mutex> lock(ctx->mu);
             auto &slot = ctx->side[st];
@@ -138,16 +150,22 @@ int for_sub_batches(fhe_ctx *ctx, hipStream_t st, size_t n_poly, size_t per, siz
         HIP_TRY(hipStreamWaitEvent(sd->s, sd->fork, 0));
     }
     hipError_t e = hipSuccess;
-    size_t i = 0;
-    for (size_t p0 = 0; p0 < n_poly && e == hipSuccess; p0 += per, ++i) {
+    for (size_t i = 0; i < n_pieces && e == hipSuccess; ++i) {
         const bool on_side = sd && (i & 1);
-        e = fn(on_side ? sd->s : st, p0, std::min(per, n_poly - p0), on_side && side_tmp_bytes ? sd->tmp.as<u64>() : nullptr);
+        e = fn(on_side ? sd->s : st, i, on_side && side_tmp_bytes ? sd->tmp.as<u64>() : nullptr);
     }
     if (sd) {   // join even after a failed launch: the side stream must not be left forked
         HIP_TRY(hipEventRecord(sd->join, sd->s));
         HIP_TRY(hipStreamWaitEvent(st, sd->join, 0));
     }
     return e == hipSuccess ? FHE_OK : hip_fail(e, "sub-batch launch");
+}
+// pieces of `per` polynomials: fn(stream, first polynomial, count, side scratch)
+int for_sub_batches(fhe_ctx *ctx, hipStream_t st, size_t n_poly, size_t per, size_t side_tmp_bytes,
+                    const std::function<hipError_t(hipStream_t, size_t, size_t, u64 *)> &fn)
+{
+    return for_pieces(ctx, st, (n_poly + per - 1) / per, side_tmp_bytes,
+                      [&](hipStream_t s, size_t i, u64 *side_tmp) { return fn(s, i * per, std::min(per, n_poly - i * per), side_tmp); });
 }
 
 // d_src (optional): out-of-place -- the input is read from there (same layout), nothing is copied (PassArgs::src)
@@ -234,27 +252,33 @@ int ntt_batch(fhe_ctx *ctx, u64 *d, const fhe_ntt_tables *t, size_t n_poly, size
             // second launch then finds the first one's output on-die (512 MiB / 2 GiB batches: 0.30 -> 0.34 of the roofline,
             // profiles/r02_chunk_sweep.txt, r02_split_sweep.txt).  Limb-major launch order keeps whole limbs together.
             const bool plain = t->log_n >= 13 && ctx->only_pass < 0 && !a.scratch;
-            const size_t per = plain ? sub_batch_polys(ctx, t->log_n, n_poly, len) : 0;
+            const SubBatchCut cut = plain ? sub_batch_cut(ctx, t->log_n, n_poly, len) : SubBatchCut{0, 0};
             u64 *pp = nullptr;
             // hand-off through a per-stream scratch (both launches out of place); by default only for calls that are sub-batched, i.e.
             // stream from HBM anyway: for a batch that fits the Infinity Cache the scratch would double the footprint and push it out
-            const bool want_pp = ctx->pingpong < 0 ? per != 0 : ctx->pingpong != 0;
-            const size_t pp_bytes = (per ? per : n_poly) * limbs * N * 8;      // one sub-batch (or the whole call) in the data's own layout
-            if (want_pp && plain) {
-                HIP_TRY(handoff_scratch(ctx, st, pp_bytes, &pp));
-                if (pp) pp += off * N;
-            }
-            if (per) {
-                return for_sub_batches(ctx, st, n_poly, per, pp ? pp_bytes : 0, [&](hipStream_t s, size_t p0, size_t cnt, u64 *side_tmp) {
+            const bool want_pp = !galois && (ctx->pingpong < 0 ? cut.pc != 0 : ctx->pingpong != 0);
+            // one piece, compact ([pc][lc][N]), or the whole call in the data's own layout
+            const size_t pp_bytes = (cut.pc ? cut.pc * cut.lc : n_poly * limbs) * N * 8;
+            if (want_pp && plain) HIP_TRY(handoff_scratch(ctx, st, pp_bytes, &pp));
+            if (cut.pc) {
+                const size_t npp = (n_poly + cut.pc - 1) / cut.pc, npl = (len + cut.lc - 1) / cut.lc;
+                return for_pieces(ctx, st, npp * npl, pp ? pp_bytes : 0, [&](hipStream_t s, size_t i, u64 *side_tmp) {
+                    // (pieces of one limb window follow each other: its tables stay in the L2s)
+                    const size_t l0 = (i / npp) * cut.lc, p0 = (i % npp) * cut.pc;
+                    const size_t lc = std::min(cut.lc, len - l0), pc = std::min(cut.pc, n_poly - p0);
                     PassArgs c = a;
-                    c.data = a.data + p0 * limbs * N;
-                    if (a.src) c.src = a.src + p0 * limbs * N;
-                    c.units = (u32)(cnt * len);
-                    c.tmp = side_tmp ? side_tmp + off * N : pp;
+                    c.data = a.data + (p0 * limbs + l0) * N;
+                    if (a.src) c.src = a.src + (p0 * limbs + l0) * N;
+                    if (a.galois_copy) c.galois_copy = a.galois_copy + (p0 * limbs + l0) * N;
+                    c.limb0 = a.limb0 + (u32)l0;
+                    c.limbs = (u32)lc;
+                    c.units = (u32)(pc * lc);
+                    c.tmp = side_tmp ? side_tmp : pp;
+                    c.tmp_stride = (u32)lc;
                     return launch_ntt(s, c, t->log_n, inverse, path, ctx->geo, -1, false);
                 });
             } else {
-                a.tmp = pp;
+                a.tmp = pp ? pp + off * N : nullptr;
                 e = launch_ntt(st, a, t->log_n, inverse, path, ctx->geo, ctx->only_pass, ctx->resident);
             }
         }

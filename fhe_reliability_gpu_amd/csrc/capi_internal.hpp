@@ -310,7 +310,12 @@ int keyswitch_core(fhe_ctx *ctx, fhe_keyswitch *p, uint64_t *d_out0, uint64_t *d
 int build_tables(fhe_ctx *ctx, int log_n, const fhe::u64 *q, int count, const fhe::u64 *fwd_rows, bool want_inverse, int force_path,
                  const fhe::u64 *psi_or_null, fhe_ntt_tables **out, const fhe::u64 *gs_scale = nullptr);
 int cyclic_tables(fhe_ctx *ctx, int log_n, fhe::u64 mod, fhe::u64 root, int convention, fhe::u64 scale, fhe_ntt_tables **out);
+struct SubBatchCut {
+    size_t pc, lc;      // polynomials x limbs per piece; pc = 0: no cut
+};
+SubBatchCut sub_batch_cut(const fhe_ctx *ctx, int log_n, size_t n_poly, size_t len);
 size_t sub_batch_polys(const fhe_ctx *ctx, int log_n, size_t n_poly, size_t len);
+int for_pieces(fhe_ctx *ctx, hipStream_t st, size_t n_pieces, size_t side_tmp_bytes, const std::function<hipError_t(hipStream_t, size_t, fhe::u64 *)> &fn);
 hipError_t handoff_scratch(fhe_ctx *ctx, hipStream_t st, size_t bytes, fhe::u64 **out);
 int for_sub_batches(fhe_ctx *ctx, hipStream_t st, size_t n_poly, size_t per, size_t side_tmp_bytes,
                     const std::function<hipError_t(hipStream_t, size_t, size_t, fhe::u64 *)> &fn);

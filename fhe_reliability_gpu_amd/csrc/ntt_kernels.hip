@@ -28,6 +28,10 @@ FHE_D const u64 *pass_source(const PassArgs &a, const u64 *base, u32 row0)
         const u32 polys = a.units / a.limbs;
         return a.src + (size_t)(unit % polys) * a.src_bcast + toff;
     }
+    if (a.src_stride) {       // the source keeps its polynomials at another distance (compact hand-off scratch of a limb window)
+        const u32 polys = a.units / a.limbs;
+        return a.src + (((size_t)(unit % polys) * a.src_stride + unit / polys) << LOGN) + toff;
+    }
     return a.src + (base - a.data);
 }
 
@@ -233,6 +237,11 @@ static hipError_t launch_transform(hipStream_t st, const PassArgs &a, int which,
         if (!first.src) first.src = a.data;
         first.data = a.tmp;
         second.src = a.tmp;
+        if (a.tmp_stride) {
+            first.src_stride = a.poly_stride;
+            first.poly_stride = a.tmp_stride;
+            second.src_stride = a.tmp_stride;
+        }
     }
     if constexpr (!PS::G::TWO_PASS) {
         if (which == 1) return hipSuccess;

@@ -103,6 +103,8 @@ struct PassArgs {
                             // each limb's prime are taken on the load): the one-limb conversions of a rescale / a K = 1 mod-down
     const u64 *src = nullptr; // optional: the transform's FIRST launch reads its input from here (same layout as data) -- an
                             // out-of-place transform with no copy; the natural-order transforms (launch_ntt_gs) require it
+    u32 src_stride = 0;     // with src: distance between the SOURCE's polynomials in limbs when it differs from poly_stride (0 = the same)
+    u32 tmp_stride = 0;     // with tmp: the hand-off buffer's polynomial stride (0 = poly_stride) -- a compact scratch for a window of limbs
     u32 galois = 0;         // with src, inverse transforms whose first launch stages its tile (N >= 2^5): the input is sigma_k(src) -- the
                             // NTT-domain Galois map applied on the load (galois_slot, ntt_core.hpp) -- instead of src: a rotation's
                             // automorphism rides on the opening INTT of its key switch

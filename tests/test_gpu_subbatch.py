@@ -1,6 +1,7 @@
 """Sub-batched two-launch transforms (capi.cpp: sub_batch_polys / for_sub_batches): a call whose batch cannot stay in the Infinity
 Cache runs as sub-batches, alternating between the caller's stream and the context's side stream, handing over through per-stream
-scratch.  Same words as the oracle whatever the cut, the ragged tail, the arithmetic path, the stream split or the hand-off."""
+scratch.  A piece is a window of limbs x a range of polynomials (as many polynomials of as few limbs as fit).  Same words as the
+oracle whatever the cut, the ragged tails in both directions, the arithmetic path, the stream split or the hand-off."""
 import ctypes as C
 
 import numpy as np
@@ -45,7 +46,8 @@ def _oracle_forward(O, data, qs, logn, start=0):
 
 @pytest.mark.parametrize("split", [0, 1])
 @pytest.mark.parametrize("pingpong", [-1, 0, 1])
-@pytest.mark.parametrize("logn,bits,n_poly", [(13, [50, 50, 61], 37), (14, [61], 19), (16, [50], 7), (16, [50, 61], 5), (17, [50], 3)])
+@pytest.mark.parametrize("logn,bits,n_poly", [(13, [50, 50, 61], 37), (13, [50] * 5, 6), (13, [61] * 7, 3), (14, [61], 19), (16, [50], 7), (16, [50, 61], 5),
+                                              (16, [50, 50, 50], 1), (17, [50], 3)])
 def test_cut_batches_match_the_oracle(F, eng, O, small_chunks, logn, bits, n_poly, split, pingpong):
     N = 1 << logn
     eng.set_option("ntt_split", split)
