@@ -80,11 +80,14 @@ int build_tables(fhe_ctx *ctx, int log_n, const u64 *q, int count, const u64 *fw
 // x `lc` limbs of the run: as many polynomials of as few limbs as fit, so that a piece works with few twiddle tables (a table is
 // fetched once per piece and XCD: 16 limbs x 8 polynomials per piece cost 0.27 of the roofline where 2 limbs x 64 cost 0.30).
 // pc = 0: one launch pair for the whole batch.
-SubBatchCut sub_batch_cut(const fhe_ctx *ctx, int log_n, size_t n_poly, size_t len)
+// bufs: buffers of the batch's shape a piece works on (a negacyclic product: both operands and the result).
+SubBatchCut sub_batch_cut(const fhe_ctx *ctx, int log_n, size_t n_poly, size_t len, size_t bufs)
 {
-    const size_t unit_bytes = (size_t)8 << log_n, total = n_poly * len * unit_bytes, chunk_bytes = (size_t)ctx->chunk_mib << 20;
-    if (!chunk_bytes || log_n < 13 || n_poly * len < 2 || total <= std::max(chunk_bytes + (chunk_bytes >> 1), (size_t)ctx->chunk_floor_mib << 20))
-        return SubBatchCut{0, 0};
+    // (a product's pieces run four launches each: they pay from twice the size and only on batches well past the cache --
+    // profiles/r02_polymul_sweep.txt: 384 MiB of operands + result 0.46 whole / 0.45 cut, 1.5 GiB 0.47 whole / 0.51 in 128 MiB pieces)
+    const size_t unit_bytes = ((size_t)8 << log_n) * bufs, total = n_poly * len * unit_bytes, chunk_bytes = ((size_t)ctx->chunk_mib << 20) * (bufs > 1 ? 2 : 1);
+    const size_t floor_bytes = ((size_t)ctx->chunk_floor_mib << 20) * (bufs > 1 ? 3 : 1);
+    if (!chunk_bytes || log_n < 13 || n_poly * len < 2 || total <= std::max(chunk_bytes + (chunk_bytes >> 1), floor_bytes)) return SubBatchCut{0, 0};
     const size_t pc = std::min(n_poly, std::max<size_t>(1, chunk_bytes / unit_bytes));
     const size_t lc = std::min(len, std::max<size_t>(1, chunk_bytes / (unit_bytes * pc)));
     if (pc == n_poly && lc == len) return SubBatchCut{0, 0};
@@ -785,6 +788,23 @@ int fhe_polymul(fhe_ctx *ctx, uint64_t *c, uint64_t *a, uint64_t *b, const fhe_n
         TraceScope tr(ctx, st, "POLYMUL");
         return for_each_run(t, limbs, start_idx, [&](size_t off, size_t len, int path) -> int {
             PassArgs pa{a + off * N, t->d_lp.as<LimbParams>(), (u32)(start_idx + off), (u32)len, (u32)(n_poly * len), (u32)limbs};
+            // operands + result that cannot stay in the Infinity Cache together: pieces that can (limb windows x polynomial ranges,
+            // alternating between the caller's stream and the side stream), so that the middle launch and the inverse column pass
+            // find their inputs on-die
+            const SubBatchCut cut = ctx->only_pass < 0 ? sub_batch_cut(ctx, t->log_n, n_poly, len, a == b ? 2 : 3) : SubBatchCut{0, 0};
+            if (cut.pc) {
+                const size_t npp = (n_poly + cut.pc - 1) / cut.pc, npl = (len + cut.lc - 1) / cut.lc;
+                return for_pieces(ctx, st, npp * npl, 0, [&](hipStream_t s, size_t i, u64 *) {
+                    const size_t l0 = (i / npp) * cut.lc, p0 = (i % npp) * cut.pc, o = (p0 * limbs + l0) * N;
+                    const size_t lc = std::min(cut.lc, len - l0), pc = std::min(cut.pc, n_poly - p0);
+                    PassArgs w = pa;
+                    w.data = pa.data + o;
+                    w.limb0 = pa.limb0 + (u32)l0;
+                    w.limbs = (u32)lc;
+                    w.units = (u32)(pc * lc);
+                    return launch_polymul(s, w, b + off * N + o, c + off * N + o, t->log_n, path);
+                });
+            }
             hipError_t e = launch_polymul(st, pa, b + off * N, c + off * N, t->log_n, path);
             if (e != hipSuccess) return hip_fail(e, "launch_polymul");
             return FHE_OK;

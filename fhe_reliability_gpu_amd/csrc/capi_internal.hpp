@@ -313,7 +313,7 @@ int cyclic_tables(fhe_ctx *ctx, int log_n, fhe::u64 mod, fhe::u64 root, int conv
 struct SubBatchCut {
     size_t pc, lc;      // polynomials x limbs per piece; pc = 0: no cut
 };
-SubBatchCut sub_batch_cut(const fhe_ctx *ctx, int log_n, size_t n_poly, size_t len);
+SubBatchCut sub_batch_cut(const fhe_ctx *ctx, int log_n, size_t n_poly, size_t len, size_t bufs = 1);
 size_t sub_batch_polys(const fhe_ctx *ctx, int log_n, size_t n_poly, size_t len);
 int for_pieces(fhe_ctx *ctx, hipStream_t st, size_t n_pieces, size_t side_tmp_bytes, const std::function<hipError_t(hipStream_t, size_t, fhe::u64 *)> &fn);
 hipError_t handoff_scratch(fhe_ctx *ctx, hipStream_t st, size_t bytes, fhe::u64 **out);

@@ -167,3 +167,32 @@ def test_default_policy_on_a_batch_that_streams_from_hbm(F, eng, O):
     eng.sync()
     assert torch.equal(a, src)
     eng.check()
+
+
+@pytest.mark.parametrize("split", [0, 1])
+@pytest.mark.parametrize("logn,bits,n_poly", [(13, [50, 61, 50, 50, 50], 7), (14, [50, 50], 9), (16, [50, 61], 3)])
+def test_negacyclic_product_cut_into_pieces(F, eng, O, small_chunks, logn, bits, n_poly, split):
+    """fhe_polymul of operands that (with the result) exceed the sub-batch size runs piece by piece -- limb windows x polynomial
+    ranges on alternating streams: same words as the oracle's product, with the result in its own buffer, aliasing an operand, and
+    for a square."""
+    N = 1 << logn
+    eng.set_option("ntt_split", split)
+    qs = F.create_moduli(N, bits)
+    t = eng.tables(logn, qs)
+    rng = np.random.default_rng(logn + n_poly)
+    a = np.stack([np.stack([rng.integers(0, q, N, dtype=np.uint64) for q in qs]) for _ in range(n_poly)])
+    b = np.stack([np.stack([rng.integers(0, q, N, dtype=np.uint64) for q in qs]) for _ in range(n_poly)])
+    want, sq = np.empty_like(a), np.empty_like(a)
+    for p in range(n_poly):
+        for l, q in enumerate(qs):
+            want[p, l] = O.polymul_ntt(a[p, l], b[p, l], t.psi[l], q)
+            sq[p, l] = O.polymul_ntt(a[p, l], a[p, l], t.psi[l], q)
+    da, db, dc = eng.upload(a), eng.upload(b), eng.upload(np.zeros_like(a))
+    t.polymul(dc, da, db, n_poly=n_poly)
+    assert (dc.download().reshape(a.shape) == want).all()
+    da, db = eng.upload(a), eng.upload(b)
+    t.polymul(da, da, db, n_poly=n_poly)                    # the result aliases the first operand
+    assert (da.download().reshape(a.shape) == want).all()
+    da = eng.upload(a)
+    t.polymul(dc, da, da, n_poly=n_poly)                    # squaring: both factors one buffer
+    assert (dc.download().reshape(a.shape) == sq).all()
