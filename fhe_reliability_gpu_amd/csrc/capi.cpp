@@ -620,6 +620,32 @@ int fhe_bitrev_permute(fhe_ctx *ctx, uint64_t *d_dst, const uint64_t *d_src, int
     return FHE_OK;
 }
 
+// Natural-order transform of n_vec vectors (two launches through a hand-off buffer, launch_ntt_gs).  Batches that cannot stay in the
+// Infinity Cache run as sub-batches on alternating streams like the negacyclic transforms (ntt_batch), each stream handing over through
+// its own scratch of one sub-batch; d_tmp_full (whole-batch hand-off buffer, may be null when the batch is cut) serves the others.
+static int gs_batch(fhe_ctx *ctx, hipStream_t st, u64 *d_dst, const u64 *d_src, const fhe_ntt_tables *t, int log_n, size_t n_vec, u64 *d_tmp_full)
+{
+    const size_t N = (size_t)1 << log_n;
+    const LimbParams *lp = t->d_lp.as<LimbParams>();
+    const int path = t->path[0];
+    if (const size_t per = sub_batch_polys(ctx, log_n, n_vec, 1)) {
+        u64 *pp = nullptr;
+        HIP_TRY(handoff_scratch(ctx, st, per * N * 8, &pp));
+        if (pp)
+            return for_sub_batches(ctx, st, n_vec, per, per * N * 8, [&](hipStream_t s, size_t p0, size_t cnt, u64 *side_tmp) {
+                PassArgs a{d_dst + p0 * N, lp, 0u, 1u, (u32)cnt, 1u};
+                a.src = d_src + p0 * N;
+                return launch_ntt_gs(s, a, side_tmp ? side_tmp : pp, log_n, path);
+            });
+    }
+    if (!d_tmp_full) return fail(FHE_ERR_INVALID, "no hand-off buffer");
+    PassArgs a{d_dst, lp, 0u, 1u, (u32)n_vec, 1u};
+    a.src = d_src;
+    hipError_t e = launch_ntt_gs(st, a, d_tmp_full, log_n, path);
+    if (e != hipSuccess) return hip_fail(e, "launch_ntt_gs");
+    return FHE_OK;
+}
+
 int fhe_ntt_cyclic(fhe_ctx *ctx, uint64_t *d_data, uint64_t *d_scratch, int log_n, size_t n_vec, uint64_t mod, uint64_t root,
                    int convention, int inverse, void *stream)
 {
@@ -641,11 +667,7 @@ int fhe_ntt_cyclic(fhe_ctx *ctx, uint64_t *d_data, uint64_t *d_scratch, int log_
     HIP_TRY(hipSetDevice(ctx->device));
     hipStream_t st = pick(ctx, stream);
     // two launches, the bit reversal folded into the first one's loads, the scale into the last stage: d_data -> d_scratch -> d_data
-    PassArgs a{d_data, t->d_lp.as<LimbParams>(), 0u, 1u, (u32)n_vec, 1u};
-    a.src = d_data;
-    hipError_t e = launch_ntt_gs(st, a, d_scratch, log_n, t->path[0]);
-    if (e != hipSuccess) return hip_fail(e, "launch_ntt_gs");
-    return FHE_OK;
+    return gs_batch(ctx, st, d_data, d_data, t, log_n, n_vec, d_scratch);
 }
 
 // ---------------------------------------------------------------- four-step
@@ -694,7 +716,8 @@ int fhe_fourstep_ntt_batch(fhe_ctx *ctx, uint64_t *d_dst, const uint64_t *d_src,
     HIP_TRY(hipSetDevice(ctx->device));
     hipStream_t st = pick(ctx, stream);
     const size_t words = n_vec << p->log_n;
-    if (p->tmp.bytes < words * 8) {
+    const bool cut = p->t && sub_batch_polys(ctx, p->log_n, n_vec, 1) != 0;      // (then the hand-off goes through per-stream scratch)
+    if (!cut && p->tmp.bytes < words * 8) {
         HIP_TRY(hipStreamSynchronize(st));      // growing frees the old block
         HIP_TRY(p->tmp.alloc(words * 8));
     }
@@ -703,11 +726,13 @@ int fhe_fourstep_ntt_batch(fhe_ctx *ctx, uint64_t *d_dst, const uint64_t *d_src,
         if (d_dst != d_src) HIP_TRY(hipMemcpyAsync(d_dst, d_src, words * 8, hipMemcpyDeviceToDevice, st));
         return fhe_ntt_cyclic(ctx, d_dst, p->tmp.as<u64>(), p->log_n, n_vec, p->mod, p->g, 0, 0, st);
     }
-    PassArgs a{d_dst, p->t->d_lp.as<LimbParams>(), 0u, 1u, (u32)n_vec, 1u};
-    a.src = d_src;
-    hipError_t e = launch_ntt_gs(st, a, p->tmp.as<u64>(), p->log_n, p->t->path[0]);
-    if (e != hipSuccess) return hip_fail(e, "launch_ntt_gs");
-    return FHE_OK;
+    if (cut && p->tmp.bytes < words * 8) {
+        // (inside a stream capture the scratch may be unavailable: the whole-batch buffer is the fallback and has to exist)
+        hipStreamCaptureStatus cap = hipStreamCaptureStatusNone;
+        (void)hipStreamIsCapturing(st, &cap);
+        if (cap != hipStreamCaptureStatusNone) return fail(FHE_ERR_INVALID, "first call of this batch size inside a stream capture: run it once outside");
+    }
+    return gs_batch(ctx, st, d_dst, d_src, p->t, p->log_n, n_vec, p->tmp.bytes >= words * 8 ? p->tmp.as<u64>() : nullptr);
 }
 
 int fhe_fourstep_ntt(fhe_ctx *ctx, uint64_t *d_dst, const uint64_t *d_src, fhe_fourstep *p, void *stream)

@@ -196,3 +196,22 @@ def test_negacyclic_product_cut_into_pieces(F, eng, O, small_chunks, logn, bits,
     da = eng.upload(a)
     t.polymul(dc, da, da, n_poly=n_poly)                    # squaring: both factors one buffer
     assert (dc.download().reshape(a.shape) == sq).all()
+
+
+@pytest.mark.parametrize("split", [0, 1])
+@pytest.mark.parametrize("logn,n_vec", [(13, 40), (14, 21), (16, 7)])
+def test_natural_order_transforms_cut_the_same_way(F, eng, O, small_chunks, logn, n_vec, split):
+    """The batched four-step / cyclic transform (two launches through a hand-off buffer) of a batch past the sub-batch size: pieces on
+    alternating streams, each stream's own scratch as the hand-off; forward against the oracle's cyclic transform, then the inverse back."""
+    from fhe_reliability_gpu_amd._lib import check, lib
+    eng.set_option("ntt_split", split)
+    mod, g = 998244353, 3
+    N = 1 << logn
+    rng = np.random.default_rng(logn + n_vec)
+    a = rng.integers(0, mod, (n_vec, N), dtype=np.uint64)
+    got = np.array(F.four_step_ntt(a, N, mod, g, n1=1 << (logn // 2)), dtype=np.uint64)
+    for v in range(n_vec):
+        assert (got[v] == O.ntt_cyclic(a[v], mod, g)).all()
+    d, s = eng.upload(got), eng.alloc(got.size)
+    check(lib.fhe_ntt_cyclic(eng._h, d.ptr, s.ptr, logn, n_vec, mod, g, 0, 1, None))
+    assert (d.download().reshape(n_vec, N) == a).all()
