@@ -278,10 +278,12 @@ int ntt_batch(fhe_ctx *ctx, u64 *d, const fhe_ntt_tables *t, size_t n_poly, size
                     c.units = (u32)(pc * lc);
                     c.tmp = side_tmp ? side_tmp : pp;
                     c.tmp_stride = (u32)lc;
+                    c.stream_hint = ctx->stream_hint != 0;       // a piece of a batch that streams from HBM
                     return launch_ntt(s, c, t->log_n, inverse, path, ctx->geo, -1, false);
                 });
             } else {
                 a.tmp = pp ? pp + off * N : nullptr;
+                a.stream_hint = ctx->stream_hint > 0;
                 e = launch_ntt(st, a, t->log_n, inverse, path, ctx->geo, ctx->only_pass, ctx->resident);
             }
         }
@@ -414,6 +416,7 @@ int fhe_ctx_set_option(fhe_ctx *ctx, const char *name, long value)
     else if (!std::strcmp(name, "tile_geo")) ctx->geo = value ? 1 : 0;
     else if (!std::strcmp(name, "ntt_resident")) ctx->resident = value != 0;
     else if (!std::strcmp(name, "ntt_packed")) ctx->packed_on = value != 0;
+    else if (!std::strcmp(name, "ntt_stream")) ctx->stream_hint = value < 0 ? -1 : value ? 1 : 0;
     else if (!std::strcmp(name, "ntt_chunk_floor_mib")) ctx->chunk_floor_mib = (unsigned)std::max(0l, value);
     else if (!std::strcmp(name, "ntt_split")) ctx->split = value < 0 ? -1 : value ? 1 : 0;
     else if (!std::strcmp(name, "ntt_pingpong")) ctx->pingpong = value < 0 ? -1 : value ? 1 : 0;

@@ -117,6 +117,7 @@ struct fhe_ctx {
     struct Side { hipStream_t s = nullptr; hipEvent_t fork = nullptr, join = nullptr; DevBuf tmp; };
     std::map<hipStream_t, std::unique_ptr<Side>> side;
     int split = -1;
+    int stream_hint = -1;  // "ntt_stream": non-temporal accesses on the external side of sub-batched transforms (-1 = when the call is cut, 0 / 1)
     unsigned chunk_floor_mib = 192;   // batches up to this size (and up to 1.5 sub-batches) are never cut
     unsigned chunk_mib = 64;  // two-launch transforms of larger batches run as sub-batches of this size (0 = off), capi.cpp ntt_batch
     int ks_fused = -1;     // key-switch inner product fused with the extended limbs' row pass: -1 = by shape, 0 = never, 1 = always (where supported)

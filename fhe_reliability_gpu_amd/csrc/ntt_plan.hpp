@@ -103,6 +103,8 @@ struct PassArgs {
                             // each limb's prime are taken on the load): the one-limb conversions of a rescale / a K = 1 mod-down
     const u64 *src = nullptr; // optional: the transform's FIRST launch reads its input from here (same layout as data) -- an
                             // out-of-place transform with no copy; the natural-order transforms (launch_ntt_gs) require it
+    u32 stream_hint = 0;    // two-launch sizes: the external side of the two launches -- the first one's loads, the second one's stores --
+                            // uses non-temporal accesses, the hand-off side stays cacheable (pieces of a batch that streams from HBM)
     u32 src_stride = 0;     // with src: distance between the SOURCE's polynomials in limbs when it differs from poly_stride (0 = the same)
     u32 tmp_stride = 0;     // with tmp: the hand-off buffer's polynomial stride (0 = poly_stride) -- a compact scratch for a window of limbs
     u32 galois = 0;         // with src, inverse transforms whose first launch stages its tile (N >= 2^5): the input is sigma_k(src) -- the
@@ -127,6 +129,11 @@ struct Passes {
                     INVERSE ? IO_CANONICAL : IO_LAZY, INVERSE ? RED_SECOND : RED_FIRST, SB> Col;
     typedef RowPass<A, typename PL::Row, LOGN, G::TR, NTT_THREADS, INVERSE, INVERSE ? IO_CANONICAL : IO_LAZY,
                     INVERSE ? IO_LAZY : IO_CANONICAL, INVERSE ? RED_FIRST : RED_SECOND, SB> Row;
+    // the same passes with non-temporal accesses on the external (canonical) side
+    typedef ColPass<A, typename PL::Col, LOGN, 0, G::TC, NTT_THREADS, INVERSE, INVERSE ? IO_LAZY : IO_CANONICAL,
+                    INVERSE ? IO_CANONICAL : IO_LAZY, INVERSE ? RED_SECOND : RED_FIRST, SB, 0, true> ColNt;
+    typedef RowPass<A, typename PL::Row, LOGN, G::TR, NTT_THREADS, INVERSE, INVERSE ? IO_CANONICAL : IO_LAZY,
+                    INVERSE ? IO_LAZY : IO_CANONICAL, INVERSE ? RED_FIRST : RED_SECOND, SB, 0, true> RowNt;
 };
 
 // LDS-resident single pass for the sizes just above the 64 KiB static limit (opt-in, "ntt_resident"): a 2^13 / 2^14

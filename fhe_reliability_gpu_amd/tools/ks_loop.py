@@ -1,5 +1,5 @@
 """Runs fhe_keyswitch_apply in a loop (random NTT-form inputs) so that rocprofv3 can break a key switch down
-by kernel:  rocprofv3 --kernel-trace --stats -d out -- python3 fhe_reliability_gpu_amd/tools/ks_loop.py 16 16 4 4 20 [rotate]"""
+by kernel:  rocprofv3 --kernel-trace --stats -d out -- python3 fhe_reliability_gpu_amd/tools/ks_loop.py 16 16 4 4 20 [rotate|hmult]"""
 import os
 import sys
 
@@ -10,6 +10,7 @@ import fhe_reliability_gpu_amd as F  # noqa: E402
 
 logn, L, K, dnum, reps = (int(x) for x in sys.argv[1:6])
 rotate = len(sys.argv) > 6 and sys.argv[6] == "rotate"
+hmult = len(sys.argv) > 6 and sys.argv[6] == "hmult"
 n = 1 << logn
 eng = F.Engine(0)
 qs = F.create_moduli(n, [50] * (L + K))
@@ -22,6 +23,8 @@ c0 = rand((L, n))
 for _ in range(reps):
     if rotate:
         ks.rotate(c0, c, 3, evk)
+    elif hmult:
+        ks.hmult(c0, c, c, c0, evk)
     else:
         ks.apply(c, evk)
 eng.sync()

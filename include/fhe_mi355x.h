@@ -64,7 +64,8 @@ int fhe_ctx_stream(fhe_ctx *ctx, void **stream_out);
  * "ntt_chunk_mib" sub-batch size of two-launch transforms of batches above "ntt_chunk_floor_mib" (192) (default 64: a sub-batch's second launch finds
  * the first one's output in the 256 MiB Infinity Cache; 0 = one launch pair for the whole batch); "ntt_split" 1 / 0 / -1 = the
  * sub-batches of one call alternate between the caller's stream and a side stream the context owns, forked and joined by events
- * (one sub-batch's row pass runs under the next one's column pass; not inside a stream capture), -1 = default = on; "ntt_pingpong" 1 / 0 / -1 = the two launches hand
+ * (one sub-batch's row pass runs under the next one's column pass; not inside a stream capture), -1 = default = on; "ntt_stream" 1 / 0 / -1 = non-temporal
+ * loads / stores on the external side of the two launches (always / never / for sub-batched calls: the default); "ntt_pingpong" 1 / 0 / -1 = the two launches hand
  * over through a per-stream scratch buffer of one sub-batch, so that both run out of place (always / never / for calls that are
  * sub-batched: the default); "ks_fused" -1 / 0 / 1 = key-switch inner product
  * fused with the extended limbs' row pass by shape / never / always;

@@ -35,7 +35,7 @@ def small_chunks(eng):
     yield
     eng.sync()
     eng.check()
-    for k, v in (("ntt_chunk_mib", 64), ("ntt_chunk_floor_mib", 192), ("ntt_split", -1), ("ntt_pingpong", -1)):
+    for k, v in (("ntt_chunk_mib", 64), ("ntt_chunk_floor_mib", 192), ("ntt_split", -1), ("ntt_pingpong", -1), ("ntt_stream", -1)):
         eng.set_option(k, v)
 
 
@@ -73,10 +73,13 @@ def test_limb_window_and_repeated_calls_reuse_the_side_stream(F, eng, O, small_c
     start, limbs = 1, 2
     data = np.stack([np.stack([rng.integers(0, q, N, dtype=np.uint64) for q in qs[start:start + limbs]]) for _ in range(n_poly)])
     want = _oracle_forward(O, data, qs[start:start + limbs], logn)
-    for _ in range(3):                               # the scratch and the fork / join events are reused call after call
+    for nt in (-1, 0, 1):                            # the scratch and the fork / join events are reused call after call;
+        eng.set_option("ntt_stream", nt)             # non-temporal accesses on the pieces' external side: by default / never / always
         d = eng.upload(data)
         t.forward(d, n_poly=n_poly, limbs=limbs, start=start)
         assert (d.download().reshape(data.shape) == want).all()
+        t.inverse(d, n_poly=n_poly, limbs=limbs, start=start)
+        assert (d.download().reshape(data.shape) == data).all()
 
 
 @pytest.mark.parametrize("pingpong", [-1, 1])
