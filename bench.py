@@ -83,7 +83,7 @@ def main():
     ap.add_argument("--check", action="store_true", help="verify one limb against the oracle before timing")
     ap.add_argument("--mode", choices=["fused", "twopass"], default="twopass")
     ap.add_argument("--no-extras", action="store_true", help="skip the secondary measurements (other batch shapes, composites)")
-    ap.add_argument("--chunk-mib", type=int, default=64, help="sub-batch size of each library call (0 = whole slab per launch pair)")
+    ap.add_argument("--chunk-mib", type=int, default=96, help="sub-batch size of each library call (0 = whole slab per launch pair)")
     ap.add_argument("--streams", type=int, default=2,
                     help="HIP streams the batch's polynomials are sharded over inside one GPU (each step = one call per stream)")
     args = ap.parse_args()
@@ -117,7 +117,7 @@ def main():
     eng = F.Engine(local_rank)
     eng.set_option("ntt_mode", 1 if args.mode == "fused" else 0)
     # each library call transforms its slab as sub-batches of this size, so that a sub-batch's second launch finds the first
-    # one's output in the 256 MiB Infinity Cache (profiles/r02_variant_sweep.txt: 64 MiB is the best size with two streams)
+    # one's output in the 256 MiB Infinity Cache (profiles/r02_split_sweep.txt: 96-112 MiB is the best size once the pieces' external side uses non-temporal accesses)
     eng.set_option("ntt_chunk_mib", args.chunk_mib)
     # the headline loop feeds --streams streams of its own: the library's own side stream ("ntt_split") stays off there
     eng.set_option("ntt_split", 0 if args.streams > 1 else -1)
@@ -281,7 +281,7 @@ def main():
         eng.set_option("ntt_chunk_mib", 0)
         one_stream_ms = timed_loop(step, 100, 10)
         result["roofline"]["ms_per_step_one_call_whole_batch_launches"] = one_stream_ms
-        eng.set_option("ntt_chunk_mib", 64)
+        eng.set_option("ntt_chunk_mib", 96)
         eng.set_option("ntt_split", -1)
         one_call_ms = timed_loop(step, 200, 20)
         result["roofline"]["ms_per_step_one_call_library_defaults"] = one_call_ms
@@ -303,8 +303,8 @@ def main():
 
     extras = not args.no_extras
     also = {}
-    # everything below is one library call per step with the library's defaults (64 MiB sub-batches, side stream)
-    eng.set_option("ntt_chunk_mib", 64)
+    # everything below is one library call per step with the library's defaults (96 MiB sub-batches, side stream)
+    eng.set_option("ntt_chunk_mib", 96)
     eng.set_option("ntt_split", -1)
 
     # ------------------------------------------------------------------ secondary measurements (rank 0, one GPU)
@@ -478,7 +478,7 @@ def main():
             return {"abft_checked_forward_same_batch": {"ms_per_step_device": ms, "unchecked_ms_same_stream": base,
                                                         "overhead_vs_unchecked_same_stream": ms / base - 1.0,
                                                         "note": "both sides: one library call per step on one caller stream, library defaults "
-                                                                "(64 MiB sub-batches, side stream, ping-pong hand-off)",
+                                                                "(96 MiB sub-batches, side stream, ping-pong hand-off)",
                                                         "flags_raised": int(flags.sum().item())}}
         also.update(abft_rate())
 

@@ -119,7 +119,7 @@ struct fhe_ctx {
     int split = -1;
     int stream_hint = -1;  // "ntt_stream": non-temporal accesses on the external side of sub-batched transforms (-1 = when the call is cut, 0 / 1)
     unsigned chunk_floor_mib = 192;   // batches up to this size (and up to 1.5 sub-batches) are never cut
-    unsigned chunk_mib = 64;  // two-launch transforms of larger batches run as sub-batches of this size (0 = off), capi.cpp ntt_batch
+    unsigned chunk_mib = 96;  // two-launch transforms of larger batches run as sub-batches of this size (0 = off), capi.cpp ntt_batch
     int ks_fused = -1;     // key-switch inner product fused with the extended limbs' row pass: -1 = by shape, 0 = never, 1 = always (where supported)
     int only_pass = -1;    // measurement hook: 0 / 1 = launch only the first / second pass of a two-pass size
     int fused_variant = 7;   // handoff*2 + stream hint (ntt_launch.hpp); 7 = acquire + nt streaming

@@ -970,7 +970,11 @@ __global__ __launch_bounds__(NTT_THREADS, 2) void k_ks_rowmac(KsMacArgs a)
                 const size_t off = (size_t)row * FR::NPTS + g;
                 ulonglong2 cw = ulonglong2{0, 0};
                 if (own) cw = *reinterpret_cast<const ulonglong2 *>(a.c + ((size_t)jj << LOGN) + toff + off);
-                ulonglong2 w0 = *reinterpret_cast<const ulonglong2 *>(k0 + off), w1 = *reinterpret_cast<const ulonglong2 *>(k1 + off);
+                // key words are touched once per call and the shapes that come here carry hundreds of MiB of them: non-temporal
+                // loads, so that they do not push the digits' tiles and the sums out of the caches
+                typedef u64 u64x2 __attribute__((ext_vector_type(2)));
+                const u64x2 v0 = __builtin_nontemporal_load(reinterpret_cast<const u64x2 *>(k0 + off)), v1 = __builtin_nontemporal_load(reinterpret_cast<const u64x2 *>(k1 + off));
+                ulonglong2 w0 = ulonglong2{v0.x, v0.y}, w1 = ulonglong2{v1.x, v1.y};
                 // words outside [0, q) (bit-flipped inputs, reliability_test/dotprod_test.cu:38-61) take ONE cold branch; no calls on the hot path
                 if (__builtin_expect((cw.x >= p.q) | (cw.y >= p.q) | (w0.x >= p.q) | (w0.y >= p.q) | (w1.x >= p.q) | (w1.y >= p.q), 0)) {
                     cw.x = barrett128(cw.x, 0, p.q, p.barrett_lo, p.barrett_hi);

@@ -42,7 +42,7 @@ def measure(reps=60):
 
 
 for rnd in range(2):
-    for chunk in (32, 64, 128):
+    for chunk in (80, 96, 112, 128, 160):
         for split in (0, 1):
             eng.set_option("ntt_chunk_mib", chunk)
             eng.set_option("ntt_split", split)

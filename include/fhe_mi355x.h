@@ -61,7 +61,7 @@ int fhe_ctx_stream(fhe_ctx *ctx, void **stream_out);
  * (their limb fits a CU's 160 KiB of LDS; experimental), 0 (default) = two launches like the larger sizes;
  * "ntt_packed" 1 = the forward 2^16 transform of FP64 limbs hands its intermediate over as packed 50-bit residues
  * (fewer bytes, more arithmetic: measured slower, experimental), 0 (default) = 8-byte words in place;
- * "ntt_chunk_mib" sub-batch size of two-launch transforms of batches above "ntt_chunk_floor_mib" (192) (default 64: a sub-batch's second launch finds
+ * "ntt_chunk_mib" sub-batch size of two-launch transforms of batches above "ntt_chunk_floor_mib" (192) (default 96: a sub-batch's second launch finds
  * the first one's output in the 256 MiB Infinity Cache; 0 = one launch pair for the whole batch); "ntt_split" 1 / 0 / -1 = the
  * sub-batches of one call alternate between the caller's stream and a side stream the context owns, forked and joined by events
  * (one sub-batch's row pass runs under the next one's column pass; not inside a stream capture), -1 = default = on; "ntt_stream" 1 / 0 / -1 = non-temporal

@@ -35,7 +35,7 @@ def small_chunks(eng):
     yield
     eng.sync()
     eng.check()
-    for k, v in (("ntt_chunk_mib", 64), ("ntt_chunk_floor_mib", 192), ("ntt_split", -1), ("ntt_pingpong", -1), ("ntt_stream", -1)):
+    for k, v in (("ntt_chunk_mib", 96), ("ntt_chunk_floor_mib", 192), ("ntt_split", -1), ("ntt_pingpong", -1), ("ntt_stream", -1)):
         eng.set_option(k, v)
 
 
@@ -142,7 +142,7 @@ def test_capture_keeps_the_sub_batches_on_the_capturing_stream(F, eng, small_chu
 
 
 def test_default_policy_on_a_batch_that_streams_from_hbm(F, eng, O):
-    """Library defaults on 208 MiB (416 polynomials of N = 2^16: four sub-batches of 64 MiB, the last one ragged): equal to the
+    """Library defaults on 208 MiB (416 polynomials of N = 2^16: sub-batches of 96 MiB, the last one ragged): equal to the
     same call made as one launch pair, and to the oracle on a polynomial of each sub-batch."""
     import torch
     from fhe_reliability_gpu_amd._lib import check, lib
@@ -161,10 +161,10 @@ def test_default_policy_on_a_batch_that_streams_from_hbm(F, eng, O):
         check(lib.fhe_ntt_forward_batch(eng._h, C.c_void_p(b.data_ptr()), t._h, n_poly, 1, 0, None))
         eng.sync()
     finally:
-        eng.set_option("ntt_chunk_mib", 64)
+        eng.set_option("ntt_chunk_mib", 96)
     assert torch.equal(a, b)
     rp = O.root_powers(qs[0], logn)
-    for p in (0, 127, 128, 300, 415):
+    for p in (0, 191, 192, 383, 384, 415):
         assert (a[p].cpu().numpy().view(np.uint64) == O.nwt_forward(src[p].cpu().numpy().view(np.uint64), qs[0], rp)).all()
     check(lib.fhe_ntt_inverse_batch(eng._h, C.c_void_p(a.data_ptr()), t._h, n_poly, 1, 0, None))
     eng.sync()
