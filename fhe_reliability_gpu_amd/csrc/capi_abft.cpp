@@ -182,6 +182,7 @@ int fhe_ntt_forward_checked(fhe_ctx *ctx, uint64_t *d_data, const fhe_ntt_tables
                     c.data = pa.data + p0 * limbs * N;
                     c.units = (u32)(cnt * len);
                     c.tmp = side_tmp ? side_tmp + off * N : pp ? pp + off * N : nullptr;
+                    c.stream_hint = ctx->stream_hint != 0;
                     return launch_ntt_checked(s, c, a->win.as<Tw>(), a->wout.as<Tw>(), a->wout8.as<u64>(), si + p0 * limbs * tin, so + p0 * limbs * tout, t->log_n, path);
                 });
             }
@@ -257,6 +258,7 @@ int fhe_ntt_forward_checked_phases(fhe_ctx *ctx, uint64_t *d_data, const fhe_ntt
                     c.data = pa.data + p0 * limbs * N;
                     c.units = (u32)(cnt * len);
                     c.tmp = side_tmp ? side_tmp + off * N : pp ? pp + off * N : nullptr;
+                    c.stream_hint = ctx->stream_hint != 0;
                     PhaseArgs c1 = p1, c2 = p2;
                     c1.sum_a += p0 * limbs * tc, c1.sum_b += p0 * limbs * tc;
                     c2.sum_a += p0 * limbs * tr, c2.sum_b += p0 * limbs * tr;

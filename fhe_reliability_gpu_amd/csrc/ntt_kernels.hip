@@ -246,13 +246,14 @@ static hipError_t launch_transform(hipStream_t st, const PassArgs &a, int which,
     if constexpr (!PS::G::TWO_PASS) {
         if (which == 1) return hipSuccess;
         return launch_pass<typename PS::Single, LOGN, INV, false>(st, a);
-    } else if (GEO == 1 && a.stream_hint && which == -1) {
+    } else if (GEO == 1 && a.stream_hint) {
         // pieces of a batch that streams from HBM: non-temporal accesses on the external side (the first launch's loads, the second
         // one's stores), so that the Infinity Cache keeps the hand-off and not words that are touched once (+3-4 % on the 512 MiB
         // batch, -17 % on one that lives in the cache: profiles/r02_nt_sweep.txt -- hence only where the caller says so)
         if constexpr (GEO == 1) {
-            hipError_t e = INV ? launch_pass<typename PS::RowNt, LOGN, INV, false>(st, first) : launch_pass<typename PS::ColNt, LOGN, INV, true>(st, first);
-            if (e != hipSuccess) return e;
+            hipError_t e = which == 1 ? hipSuccess
+                                      : INV ? launch_pass<typename PS::RowNt, LOGN, INV, false>(st, first) : launch_pass<typename PS::ColNt, LOGN, INV, true>(st, first);
+            if (e != hipSuccess || which == 0) return e;
             return INV ? launch_pass<typename PS::ColNt, LOGN, INV, true>(st, second) : launch_pass<typename PS::RowNt, LOGN, INV, false>(st, second);
         }
         return hipErrorInvalidValue;
@@ -505,6 +506,11 @@ static hipError_t launch_checked(hipStream_t st, const PassArgs &a, const AbftAr
             first.data = a.tmp;
             second.src = a.tmp;
         }
+        if (a.stream_hint && GEO == 1) {      // pieces of a batch that streams from HBM: non-temporal accesses on the external side (launch_transform)
+            if (which != 1) hipLaunchKernelGGL((k_ntt_pass_abft<typename PS::ColNt, LOGN, true, true, false>), dim3(a.units * PS::Col::TILES), dim3(NTT_THREADS), 0, st, first, ab);
+            if (which != 0) hipLaunchKernelGGL((k_ntt_pass_abft<typename PS::RowNt, LOGN, false, false, true>), dim3(a.units * PS::Row::TILES), dim3(NTT_THREADS), 0, st, second, ab);
+            return hipGetLastError();
+        }
         if (which != 1) hipLaunchKernelGGL((k_ntt_pass_abft<typename PS::Col, LOGN, true, true, false>), dim3(a.units * PS::Col::TILES), dim3(NTT_THREADS), 0, st, first, ab);
         if (which != 0) hipLaunchKernelGGL((k_ntt_pass_abft<typename PS::Row, LOGN, false, false, true>), dim3(a.units * PS::Row::TILES), dim3(NTT_THREADS), 0, st, second, ab);
     }
@@ -566,6 +572,11 @@ static hipError_t launch_phases_t(hipStream_t st, const PassArgs &a, const Phase
             first.src = a.data;
             first.data = a.tmp;
             second.src = a.tmp;
+        }
+        if (a.stream_hint) {
+            if (which != 1) hipLaunchKernelGGL((k_ntt_pass_phase<typename PS::ColNt, LOGN, true, 0>), dim3(a.units * PS::Col::TILES), dim3(NTT_THREADS), 0, st, first, p1);
+            if (which != 0) hipLaunchKernelGGL((k_ntt_pass_phase<typename PS::RowNt, LOGN, false, 1>), dim3(a.units * PS::Row::TILES), dim3(NTT_THREADS), 0, st, second, p2);
+            return hipGetLastError();
         }
         if (which != 1) hipLaunchKernelGGL((k_ntt_pass_phase<typename PS::Col, LOGN, true, 0>), dim3(a.units * PS::Col::TILES), dim3(NTT_THREADS), 0, st, first, p1);
         if (which != 0) hipLaunchKernelGGL((k_ntt_pass_phase<typename PS::Row, LOGN, false, 1>), dim3(a.units * PS::Row::TILES), dim3(NTT_THREADS), 0, st, second, p2);
