@@ -174,9 +174,9 @@ int fhe_ntt_forward_checked(fhe_ctx *ctx, uint64_t *d_data, const fhe_ntt_tables
             if (const size_t per = sub_batch_polys(ctx, t->log_n, n_poly, len)) {
                 u64 *pp = nullptr;
                 const size_t pp_bytes = per * limbs * N * 8;
-                // (the scratch hand-off of the unchecked transform buys nothing here -- the checked passes are not purely
-                // memory-bound -- and is used only on request: 0.495 ms against 0.480 ms in place on the 512 MiB batch)
-                if (ctx->pingpong > 0) HIP_TRY(handoff_scratch(ctx, st, pp_bytes, &pp));
+                // (scratch hand-off together with the non-temporal accesses on the pieces' external side, as the unchecked transform:
+                // 430 us on the 512 MiB batch against 440 us with neither and 485-500 us with only one of the two, profiles/r02_abft_sweep.txt)
+                if (ctx->pingpong > 0 || (ctx->pingpong < 0 && ctx->stream_hint != 0)) HIP_TRY(handoff_scratch(ctx, st, pp_bytes, &pp));
                 return for_sub_batches(ctx, st, n_poly, per, pp ? pp_bytes : 0, [&](hipStream_t s, size_t p0, size_t cnt, u64 *side_tmp) {
                     PassArgs c = pa;
                     c.data = pa.data + p0 * limbs * N;
@@ -250,9 +250,9 @@ int fhe_ntt_forward_checked_phases(fhe_ctx *ctx, uint64_t *d_data, const fhe_ntt
             if (const size_t per = which < 0 && fpass < 0 ? sub_batch_polys(ctx, t->log_n, n_poly, len) : 0) {
                 u64 *pp = nullptr;
                 const size_t pp_bytes = per * limbs * N * 8;
-                // (the scratch hand-off of the unchecked transform buys nothing here -- the checked passes are not purely
-                // memory-bound -- and is used only on request: 0.495 ms against 0.480 ms in place on the 512 MiB batch)
-                if (ctx->pingpong > 0) HIP_TRY(handoff_scratch(ctx, st, pp_bytes, &pp));
+                // (scratch hand-off together with the non-temporal accesses on the pieces' external side, as the unchecked transform:
+                // 430 us on the 512 MiB batch against 440 us with neither and 485-500 us with only one of the two, profiles/r02_abft_sweep.txt)
+                if (ctx->pingpong > 0 || (ctx->pingpong < 0 && ctx->stream_hint != 0)) HIP_TRY(handoff_scratch(ctx, st, pp_bytes, &pp));
                 return for_sub_batches(ctx, st, n_poly, per, pp ? pp_bytes : 0, [&](hipStream_t s, size_t p0, size_t cnt, u64 *side_tmp) {
                     PassArgs c = pa;
                     c.data = pa.data + p0 * limbs * N;
