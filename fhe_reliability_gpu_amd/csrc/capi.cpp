@@ -638,6 +638,7 @@ static int gs_batch(fhe_ctx *ctx, hipStream_t st, u64 *d_dst, const u64 *d_src, 
             return for_sub_batches(ctx, st, n_vec, per, per * N * 8, [&](hipStream_t s, size_t p0, size_t cnt, u64 *side_tmp) {
                 PassArgs a{d_dst + p0 * N, lp, 0u, 1u, (u32)cnt, 1u};
                 a.src = d_src + p0 * N;
+                a.stream_hint = ctx->stream_hint != 0;
                 return launch_ntt_gs(s, a, side_tmp ? side_tmp : pp, log_n, path);
             });
     }
@@ -830,6 +831,7 @@ int fhe_polymul(fhe_ctx *ctx, uint64_t *c, uint64_t *a, uint64_t *b, const fhe_n
                     w.limb0 = pa.limb0 + (u32)l0;
                     w.limbs = (u32)lc;
                     w.units = (u32)(pc * lc);
+                    // (no non-temporal accesses here: measured slower on the product's pieces, 0.48 against 0.51, profiles/r02_polymul_sweep.txt)
                     return launch_polymul(s, w, b + off * N + o, c + off * N + o, t->log_n, path);
                 });
             }

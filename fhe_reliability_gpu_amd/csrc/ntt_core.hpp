@@ -389,12 +389,13 @@ struct RowPass {
         return brev_bits(row0 + row, S0);
     }
     // ROWMODE 1: natural-order source (limb base) -> LDS image, bit reversal folded in
-    static FHE_D void gather_in(int tid, const u64 *__restrict__ src, u32 row0, elem *__restrict__ lds)
+    static FHE_D void gather_in(int tid, const u64 *__restrict__ src, u32 row0, elem *__restrict__ lds, bool nt_src)
     {
         for (int i = tid; i < TR * NPTS; i += NTHREADS) {
             const u32 ki = (u32)i % TR, rho = (u32)i / TR;
             const u32 k = brev_bits(rho, P);
-            const u64 v = src[((size_t)rho << S0) + row0 + ki];
+            const u64 *from = src + ((size_t)rho << S0) + row0 + ki;
+            const u64 v = nt_src ? load_stream_u64(from) : *from;      // (pieces of a batch that streams from HBM: touched once)
             lds[ki * ROW_LDS + row_pad(k)] = __builtin_bit_cast(elem, v);
         }
     }
@@ -467,10 +468,10 @@ struct RowPass {
     template <int E, class TAP = NoTap>
     static FHE_D void phase(int tid, u64 *__restrict__ base, elem *__restrict__ lds, TwPtr tw, u32 row0,
                             const typename A::Ctx &c, const Tw &inv_n, TAP *tap = nullptr, const u64 *src = nullptr, u32 galois = 0,
-                            u64 *galois_copy = nullptr)
+                            u64 *galois_copy = nullptr, bool nt_src = false)
     {
         if constexpr (STAGE_IN && E == 0) {
-            if constexpr (ROWMODE == 1) gather_in(tid, src, row0, lds);
+            if constexpr (ROWMODE == 1) gather_in(tid, src, row0, lds, nt_src);
             else if (galois && src) copy_in_galois(tid, src - (size_t)row0 * NPTS, row0, lds, galois, galois_copy);
             else copy_in(tid, src ? src : base, lds);
         } else if constexpr (STAGE_OUT && E == NPHASE - 1) {

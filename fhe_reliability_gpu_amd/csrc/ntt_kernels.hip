@@ -87,7 +87,7 @@ __global__ __launch_bounds__(NTT_THREADS) void k_ntt_gs_first(PassArgs a)
     const u32 row0 = tile * PASS::TROWS;
     u64 *base = a.data + off;
     const u64 *from = a.src + off;
-    PASS::template phase<0>(tid, base, lds, tw, row0, ctx, inv_n, (NoTap *)nullptr, from);
+    PASS::template phase<0>(tid, base, lds, tw, row0, ctx, inv_n, (NoTap *)nullptr, from, 0u, nullptr, a.stream_hint != 0);
     __syncthreads();
     PASS::template phase<1>(tid, base, lds, tw, row0, ctx, inv_n);
     if constexpr (PASS::NPHASE > 2) {
@@ -289,6 +289,9 @@ static hipError_t launch_gs_t(hipStream_t st, const PassArgs &a, u64 *tmp)
         first.data = tmp;
         second.src = tmp;
         hipLaunchKernelGGL((k_ntt_gs_first<First, LOGN>), dim3(a.units * First::TILES), dim3(NTT_THREADS), 0, st, first);
+        if (a.stream_hint && GEO == 1) {
+            if constexpr (GEO == 1) return launch_pass<typename PS::ColNt, LOGN, true, true>(st, second);
+        }
         return launch_pass<typename PS::Col, LOGN, true, true>(st, second);
     }
 }
