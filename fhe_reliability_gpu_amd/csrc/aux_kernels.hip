@@ -18,9 +18,11 @@ __device__ __forceinline__ u64 mulmod_shoup(u64 a, u64 w, u64 ws, u64 q)
 }
 
 // ---------------------------------------------------------------------------
-template <bool ACC>
+// NT: operands and result past the Infinity Cache (touched once): non-temporal accesses
+template <bool ACC, bool NT>
 __global__ __launch_bounds__(256) void k_modmul(PointwiseArgs p)
 {
+    typedef u64 u64x2 __attribute__((ext_vector_type(2)));
     const u64 n = (u64)1 << p.logn;
     const u64 total = (u64)p.units << p.logn;
     for (u64 i_ = (blockIdx.x * (u64)blockDim.x + threadIdx.x) * 2; i_ < total; i_ += (u64)gridDim.x * blockDim.x * 2) {
@@ -30,8 +32,15 @@ __global__ __launch_bounds__(256) void k_modmul(PointwiseArgs p)
         const u64 q = lp.q, r0 = lp.barrett_lo, r1 = lp.barrett_hi;
         {
             const u64 i = (((u64)poly * p.poly_stride + l) << p.logn) + (i_ & (n - 1));
-            const ulonglong2 a = *reinterpret_cast<const ulonglong2 *>(p.a + i);
-            const ulonglong2 b = *reinterpret_cast<const ulonglong2 *>(p.b + i);
+            ulonglong2 a, b;
+            if (NT) {
+                const u64x2 va = __builtin_nontemporal_load(reinterpret_cast<const u64x2 *>(p.a + i)), vb = __builtin_nontemporal_load(reinterpret_cast<const u64x2 *>(p.b + i));
+                a = ulonglong2{va.x, va.y};
+                b = ulonglong2{vb.x, vb.y};
+            } else {
+                a = *reinterpret_cast<const ulonglong2 *>(p.a + i);
+                b = *reinterpret_cast<const ulonglong2 *>(p.b + i);
+            }
             ulonglong2 c;
             c.x = mulmod_b(a.x, b.x, q, r0, r1);
             c.y = mulmod_b(a.y, b.y, q, r0, r1);
@@ -41,7 +50,8 @@ __global__ __launch_bounds__(256) void k_modmul(PointwiseArgs p)
                 c.x = x >= q ? x - q : x;
                 c.y = y >= q ? y - q : y;
             }
-            *reinterpret_cast<ulonglong2 *>(p.c + i) = c;
+            if (NT) __builtin_nontemporal_store(u64x2{c.x, c.y}, reinterpret_cast<u64x2 *>(p.c + i));
+            else *reinterpret_cast<ulonglong2 *>(p.c + i) = c;
         }
     }
 }
@@ -127,8 +137,10 @@ hipError_t launch_modmul(hipStream_t st, const PointwiseArgs &p, bool accumulate
     if (!total) return hipSuccess;
     u64 want = (total / 2 + 255) / 256;
     const u32 blocks = (u32)(want < 1 ? 1 : want > 8192 ? 8192 : want);
-    if (accumulate) hipLaunchKernelGGL(k_modmul<true>, dim3(blocks), dim3(256), 0, st, p);
-    else hipLaunchKernelGGL(k_modmul<false>, dim3(blocks), dim3(256), 0, st, p);
+    const bool nt = total * 24 > ((u64)192 << 20);      // three buffers of the batch's size
+    if (accumulate) hipLaunchKernelGGL((k_modmul<true, false>), dim3(blocks), dim3(256), 0, st, p);
+    else if (nt) hipLaunchKernelGGL((k_modmul<false, true>), dim3(blocks), dim3(256), 0, st, p);
+    else hipLaunchKernelGGL((k_modmul<false, false>), dim3(blocks), dim3(256), 0, st, p);
     return hipGetLastError();
 }
 
