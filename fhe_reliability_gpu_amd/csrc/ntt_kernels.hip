@@ -6,6 +6,7 @@
 #include "ntt_launch.hpp"
 #include "ntt_plan.hpp"
 
+#include <cstdlib>
 #include <type_traits>
 
 namespace fhe {
@@ -104,7 +105,8 @@ template <class PASS, int LOGN, bool INV, bool IS_COL>
 static hipError_t launch_pass(hipStream_t st, const PassArgs &a)
 {
     const u32 blocks = a.units * PASS::TILES;
-    hipLaunchKernelGGL((k_ntt_pass<PASS, LOGN, INV, IS_COL>), dim3(blocks), dim3(NTT_THREADS), 0, st, a);
+    static const u32 extra_lds = getenv("FHE_DBG_EXTRA_LDS") ? (u32)atoi(getenv("FHE_DBG_EXTRA_LDS")) : 0;     // occupancy experiment: dynamic LDS nobody uses
+    hipLaunchKernelGGL((k_ntt_pass<PASS, LOGN, INV, IS_COL>), dim3(blocks), dim3(NTT_THREADS), extra_lds, st, a);
     return hipGetLastError();
 }
 
