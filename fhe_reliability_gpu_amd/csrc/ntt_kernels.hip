@@ -947,7 +947,12 @@ hipError_t launch_ntt_subscale(hipStream_t st, const PassArgs &a, const RowEpiAr
 template <class A, int LOGN, int GEO>
 __global__ __launch_bounds__(NTT_THREADS, 2) void k_ks_rowmac(KsMacArgs a)
 {
-    typedef typename MidPasses<A, LOGN, GEO>::Fwd FR;
+    typedef MidPasses<A, LOGN, GEO> MP;
+    // (2^16: the row pass in three register steps of 8 / 8 / 4 points instead of two of 16 -- one more exchange through LDS, but its
+    // registers no longer compete with the 64 registers of sums: with the two-step form the kernel sat at 256 VGPRs with 49 spilled)
+    typedef typename std::conditional<LOGN == 16 && GEO == 1,
+                                      RowPass<A, Steps<3, 3, 2>, LOGN, MP::TR, NTT_THREADS, false, IO_LAZY, IO_LAZY, MP::F::RED_SECOND, MP::SB>,
+                                      typename MP::Fwd>::type FR;
     static_assert(FR::STAGED, "fused inner product needs the staged row pass");
     typedef typename FR::elem elem;
     constexpr int PAIRS = FR::TROWS * FR::NPTS / 2;
@@ -1023,7 +1028,7 @@ __global__ __launch_bounds__(NTT_THREADS, 2) void k_ks_rowmac(KsMacArgs a)
                 }
             }
 #if defined(__HIP_DEVICE_COMPILE__)
-            if (k & 1) __builtin_amdgcn_sched_barrier(0);      // keep at most two pairs' loads in flight: the sums already hold 64 registers
+            if ((k & 3) == 3) __builtin_amdgcn_sched_barrier(0);      // keep at most four pairs' loads in flight: the sums already hold 64 registers
 #endif
         }
     }
