@@ -283,7 +283,11 @@ int ntt_batch(fhe_ctx *ctx, u64 *d, const fhe_ntt_tables *t, size_t n_poly, size
                 });
             } else {
                 a.tmp = pp ? pp + off * N : nullptr;
-                a.stream_hint = ctx->stream_hint > 0;
+                // single-launch sizes have nothing to hand over and are never cut: a batch of theirs that cannot stay in the Infinity
+                // Cache is touched once in, once out -- non-temporal accesses, as for the pieces above
+                const bool streams = t->log_n < 13 && t->log_n >= 5 && ctx->stream_hint < 0 && ctx->only_pass < 0 &&
+                                     (size_t)a.units * N * 8 > ((size_t)ctx->chunk_floor_mib << 20);
+                a.stream_hint = ctx->stream_hint > 0 || streams;
                 e = launch_ntt(st, a, t->log_n, inverse, path, ctx->geo, ctx->only_pass, ctx->resident);
             }
         }

@@ -247,6 +247,7 @@ static hipError_t launch_transform(hipStream_t st, const PassArgs &a, int which,
     }
     if constexpr (!PS::G::TWO_PASS) {
         if (which == 1) return hipSuccess;
+        if (a.stream_hint && !a.src) return launch_pass<typename PS::SingleNt, LOGN, INV, false>(st, a);      // a batch that streams from HBM
         return launch_pass<typename PS::Single, LOGN, INV, false>(st, a);
     } else if (GEO == 1 && a.stream_hint) {
         // pieces of a batch that streams from HBM: non-temporal accesses on the external side (the first launch's loads, the second

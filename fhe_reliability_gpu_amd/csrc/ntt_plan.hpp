@@ -124,6 +124,7 @@ struct Passes {
     // single pass
     static constexpr int SB = BlkStage<LOGN>::value;
     typedef RowPass<A, typename PL::Row, LOGN, 1, NTT_THREADS, INVERSE, IO_CANONICAL, IO_CANONICAL, RED_FIRST, SB> Single;
+    typedef RowPass<A, typename PL::Row, LOGN, 1, NTT_THREADS, INVERSE, IO_CANONICAL, IO_CANONICAL, RED_FIRST, SB, 0, true> SingleNt;   // non-temporal loads and stores
     // forward: column pass then row pass; inverse: row pass then column pass
     typedef ColPass<A, typename PL::Col, LOGN, 0, G::TC, NTT_THREADS, INVERSE, INVERSE ? IO_LAZY : IO_CANONICAL,
                     INVERSE ? IO_CANONICAL : IO_LAZY, INVERSE ? RED_SECOND : RED_FIRST, SB> Col;

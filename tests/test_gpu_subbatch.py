@@ -217,3 +217,25 @@ def test_natural_order_transforms_cut_the_same_way(F, eng, O, small_chunks, logn
     d, s = eng.upload(got), eng.alloc(got.size)
     check(lib.fhe_ntt_cyclic(eng._h, d.ptr, s.ptr, logn, n_vec, mod, g, 0, 1, None))
     assert (d.download().reshape(n_vec, N) == a).all()
+
+
+@pytest.mark.parametrize("logn", [5, 8, 10, 11, 12])
+def test_single_launch_sizes_with_non_temporal_accesses(F, eng, O, logn):
+    """Batches of the single-launch sizes that stream from HBM run the same kernels with non-temporal loads and stores
+    ("ntt_stream" 1 forces them on a small batch): same words as the oracle, both arithmetic paths, forward and inverse."""
+    N, n_poly = 1 << logn, 5
+    qs = F.create_moduli(N, [50, 61])
+    t = eng.tables(logn, qs)
+    rng = np.random.default_rng(logn)
+    data = np.stack([np.stack([rng.integers(0, q, N, dtype=np.uint64) for q in qs]) for _ in range(n_poly)])
+    data[0, 0, :] = qs[0] - 1
+    eng.set_option("ntt_stream", 1)
+    try:
+        d = eng.upload(data)
+        t.forward(d, n_poly=n_poly)
+        assert (d.download().reshape(data.shape) == _oracle_forward(O, data, qs, logn)).all()
+        t.inverse(d, n_poly=n_poly)
+        assert (d.download().reshape(data.shape) == data).all()
+    finally:
+        eng.set_option("ntt_stream", -1)
+    eng.check()
