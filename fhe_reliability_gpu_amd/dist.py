@@ -221,6 +221,11 @@ class ShardedKeySwitch:
         check(lib.fhe_keyswitch_shard_finish(self.eng._h, self._h, self._p(out0), self._p(out1), self._p(add0), self._p(add1), self._stream()))
         return out0, out1
 
+    def set_plain_modulus(self, t: int):
+        """BGV form of the mod-down and of the rescale on this rank's rows (0 = CKKS-style flooring); every rank sets the same value."""
+        from ._lib import check, lib
+        check(lib.fhe_keyswitch_set_plain_modulus(self._h, t))
+
     # the three phases of a rotation: the automorphism rides on loads of the key switch's own launches (fhe_rotate_shard_*)
     def rotate_begin(self, c1_local, galois_elt: int):
         from ._lib import check, lib

@@ -168,16 +168,22 @@ def _gloo_gpu_worker(rank, world, port, logn, L, K, dnum, bits, out_dir):
     dist.init_process_group("gloo", rank=rank, world_size=world)
     try:
         import fhe_reliability_gpu_amd as F
-        from fhe_reliability_gpu_amd.dist import ShardedKeySwitch, ks_layout, own_ct_rows, own_rows, sharded_keyswitch
+        from fhe_reliability_gpu_amd.dist import ShardedKeySwitch, ks_layout, own_ct_rows, own_rows, sharded_keyswitch, sharded_rotate
         eng = F.Engine(0)
         qs, c, evk, add = _case(logn, L, K, dnum, bits)
         t = eng.tables(logn, qs)
         lay = ks_layout(L, K, world, rank)
         plan = ShardedKeySwitch(eng, t, L, K, dnum)
         assert plan.lay == lay
-        o0, o1 = sharded_keyswitch(plan, _to_cuda(c[own_ct_rows(lay)]), _to_cuda(evk[:, :, own_rows(lay)]), add0=_to_cuda(add[own_ct_rows(lay)]))
+        c_l, add_l, evk_l = _to_cuda(c[own_ct_rows(lay)]), _to_cuda(add[own_ct_rows(lay)]), _to_cuda(evk[:, :, own_rows(lay)])
+        o0, o1 = sharded_keyswitch(plan, c_l, evk_l, add0=add_l)
+        # a rotation (the automorphism on the loads of every rank's own launches) and the BGV form of the mod-down, same plan
+        r0, r1 = sharded_rotate(plan, add_l, c_l, 5, evk_l)
+        plan.set_plain_modulus(65537)
+        b0, b1 = sharded_keyswitch(plan, c_l, evk_l, add0=add_l)
+        plan.set_plain_modulus(0)
         torch.cuda.synchronize()
-        np.save(os.path.join(out_dir, f"g{rank}.npy"), np.stack([_from_cuda(o0), _from_cuda(o1)]))
+        np.save(os.path.join(out_dir, f"g{rank}.npy"), np.stack([_from_cuda(x) for x in (o0, o1, r0, r1, b0, b1)]))
     finally:
         dist.destroy_process_group()
 
@@ -189,7 +195,7 @@ def test_real_plan_with_ranks_sharing_the_gpu(tmp_path, world, logn, L, K, dnum,
     results equal the oracle composite.  This is the multi-rank device code the 8-GPU RCCL run executes."""
     import torch.multiprocessing as mp
     from fhe_reliability_gpu_amd.dist import ks_layout
-    from oracle.keyswitch_ref import keyswitch_ref
+    from oracle.keyswitch_ref import keyswitch_ref, rotate_ref
     mp.spawn(_gloo_gpu_worker, args=(world, _free_port(), logn, L, K, dnum, bits, str(tmp_path)), nprocs=world, join=True)
     qs, c, evk, add = _case(logn, L, K, dnum, bits)
     w0, w1 = keyswitch_ref(c, evk, qs, L, K, dnum, logn, add0=add)
@@ -197,5 +203,10 @@ def test_real_plan_with_ranks_sharing_the_gpu(tmp_path, world, logn, L, K, dnum,
     g0 = np.concatenate([g[0] for g in got], axis=0)
     g1 = np.concatenate([g[1] for g in got], axis=0)
     assert g0.shape == w0.shape and (g0 == w0).all() and (g1 == w1).all()
+    # the sharded rotation (fhe_rotate_shard_*) and the sharded BGV mod-down
+    v0, v1 = rotate_ref(add, c, 5, evk, qs, L, K, dnum, logn)
+    assert (np.concatenate([g[2] for g in got], axis=0) == v0).all() and (np.concatenate([g[3] for g in got], axis=0) == v1).all()
+    p0, p1 = keyswitch_ref(c, evk, qs, L, K, dnum, logn, add0=add, plain_modulus=65537)
+    assert (np.concatenate([g[4] for g in got], axis=0) == p0).all() and (np.concatenate([g[5] for g in got], axis=0) == p1).all()
     for r in range(world):
         assert got[r].shape[1] == ks_layout(L, K, world, r)["cn"]
