@@ -127,7 +127,7 @@ def _gloo_gpu_hmult_worker(rank, world, port, logn, L, K, dnum, bits, out_dir):
     dist.init_process_group("gloo", rank=rank, world_size=world)
     try:
         import fhe_reliability_gpu_amd as F
-        from fhe_reliability_gpu_amd.dist import ShardedKeySwitch, ks_layout, own_ct_rows, own_rows, sharded_hmult
+        from fhe_reliability_gpu_amd.dist import ShardedKeySwitch, ks_layout, own_ct_rows, own_rows, sharded_hmult, sharded_rescale
         eng = F.Engine(0)
         qs, a0, rlk, a1 = _case(logn, L, K, dnum, bits)
         _, b0, _, b1 = _case(logn, L, K, dnum, bits, seed=5)
@@ -136,8 +136,12 @@ def _gloo_gpu_hmult_worker(rank, world, port, logn, L, K, dnum, bits, out_dir):
         rows = own_ct_rows(lay)
         plan = ShardedKeySwitch(eng, t, L, K, dnum)
         o0, o1 = sharded_hmult(plan, _to_cuda(a0[rows]), _to_cuda(a1[rows]), _to_cuda(b0[rows]), _to_cuda(b1[rows]), _to_cuda(rlk[:, :, own_rows(lay)]))
+        # the BGV form of the rescale on the same plan: the owner of the last limb broadcasts t [c t^-1]_q_last's source limb
+        plan.set_plain_modulus(786433)
+        rb = sharded_rescale(plan, torch.stack([_to_cuda(a0[rows]), _to_cuda(a1[rows])]))
+        plan.set_plain_modulus(0)
         torch.cuda.synchronize()
-        np.save(os.path.join(out_dir, f"h{rank}.npy"), np.stack([_from_cuda(o0), _from_cuda(o1)]))
+        np.save(os.path.join(out_dir, f"h{rank}.npy"), np.stack([_from_cuda(o0), _from_cuda(o1), _from_cuda(rb[0]), _from_cuda(rb[1])]))
     finally:
         dist.destroy_process_group()
 
@@ -148,7 +152,7 @@ def test_sharded_hmult_real_plan(tmp_path, world, logn, L, K, dnum, bits):
     product on the owned rows, sharded relinearisation (d0 / d1 as addends of its last launch), sharded rescale (the last limb's owner
     broadcasts it) -- concatenated results equal the oracle's hmult_ref, i.e. what fhe_hmult gives on one device."""
     import torch.multiprocessing as mp
-    from oracle.keyswitch_ref import hmult_ref
+    from oracle.keyswitch_ref import hmult_ref, rescale_ref
     mp.spawn(_gloo_gpu_hmult_worker, args=(world, _free_port(), logn, L, K, dnum, bits, str(tmp_path)), nprocs=world, join=True)
     qs, a0, rlk, a1 = _case(logn, L, K, dnum, bits)
     _, b0, _, b1 = _case(logn, L, K, dnum, bits, seed=5)
@@ -157,6 +161,8 @@ def test_sharded_hmult_real_plan(tmp_path, world, logn, L, K, dnum, bits):
     g0 = np.concatenate([g[0] for g in got], axis=0)
     g1 = np.concatenate([g[1] for g in got], axis=0)
     assert g0.shape == w0.shape and (g0 == w0).all() and (g1 == w1).all()
+    rb = rescale_ref(np.stack([a0, a1]), qs, L, logn, plain_modulus=786433)          # sharded BGV rescale of (a0, a1)
+    assert (np.concatenate([g[2] for g in got], axis=0) == rb[0]).all() and (np.concatenate([g[3] for g in got], axis=0) == rb[1]).all()
 
 
 def _gloo_gpu_worker(rank, world, port, logn, L, K, dnum, bits, out_dir):
