@@ -239,3 +239,30 @@ def test_single_launch_sizes_with_non_temporal_accesses(F, eng, O, logn):
     finally:
         eng.set_option("ntt_stream", -1)
     eng.check()
+
+
+@pytest.mark.parametrize("nt", [-1, 1])
+@pytest.mark.parametrize("logn,bits", [(13, [50, 61]), (16, [50]), (17, [61])])
+def test_the_two_launches_one_at_a_time(F, eng, O, logn, bits, nt):
+    """"ntt_only_pass" 0 then 1 (bench.py times the two kernels of the headline this way, with the non-temporal variants): first
+    launch, second launch = the whole transform, forward and inverse."""
+    N, n_poly = 1 << logn, 2
+    qs = F.create_moduli(N, bits)
+    t = eng.tables(logn, qs)
+    rng = np.random.default_rng(logn)
+    data = np.stack([np.stack([rng.integers(0, q, N, dtype=np.uint64) for q in qs]) for _ in range(n_poly)])
+    eng.set_option("ntt_stream", nt)
+    try:
+        d = eng.upload(data)
+        for which in (0, 1):
+            eng.set_option("ntt_only_pass", which)
+            t.forward(d, n_poly=n_poly)
+        assert (d.download().reshape(data.shape) == _oracle_forward(O, data, qs, logn)).all()
+        for which in (0, 1):
+            eng.set_option("ntt_only_pass", which)
+            t.inverse(d, n_poly=n_poly)
+        assert (d.download().reshape(data.shape) == data).all()
+    finally:
+        eng.set_option("ntt_only_pass", -1)
+        eng.set_option("ntt_stream", -1)
+    eng.check()
