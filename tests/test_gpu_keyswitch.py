@@ -285,3 +285,56 @@ def test_rotate_with_the_automorphism_on_the_loads(F, eng, logn, L, K, dnum, bit
                 eng.set_option("ntt_resident", 0)
             assert (r0.download() == w0).all() and (r1.download() == w1).all(), f"galois element {k}, separate-launch route"
     eng.check()
+
+
+@pytest.mark.parametrize("fused", [0, 1])
+@pytest.mark.parametrize("logn,L,K,dnum,bits", [(5, 3, 1, 3, 50), (10, 4, 2, 2, 61), (13, 4, 1, 2, 61), (14, 5, 2, 3, 50)])
+def test_both_forms_of_the_inner_product(F, eng, logn, L, K, dnum, bits, fused):
+    """"ks_fused" 0 / 1 forces the key switch's inner product to run as a launch of its own after the extended limbs' row pass, or
+    fused with that row pass (the library picks by shape, so small shapes never see the fused form and the BASELINE shapes never see
+    the other one): both equal the oracle composite, on both arithmetic paths and with special primes of the other path."""
+    from oracle.keyswitch_ref import keyswitch_ref
+    N = 1 << logn
+    qs = F.create_moduli(N, [bits] * L + [50 if bits == 61 else 61] * K)       # special primes on the OTHER arithmetic path
+    t = eng.tables(logn, qs)
+    rng = np.random.default_rng(logn * 3 + fused)
+    c = np.stack([rng.integers(0, q, N, dtype=np.uint64) for q in qs[:L]])
+    add = np.stack([rng.integers(0, q, N, dtype=np.uint64) for q in qs[:L]])
+    evk = np.stack([np.stack([np.stack([rng.integers(0, q, N, dtype=np.uint64) for q in qs]) for _ in range(2)]) for _ in range(dnum)])
+    ks = F.KeySwitch(eng, t, L, K, dnum)
+    eng.set_option("ks_fused", fused)
+    try:
+        o0, o1 = ks.apply(eng.upload(c), eng.upload(evk))
+        w0, w1 = keyswitch_ref(c, evk, qs, L, K, dnum, logn)
+        assert (o0.download() == w0).all() and (o1.download() == w1).all()
+        d0, d1, d2 = eng.upload(add), eng.upload(c), eng.upload(c)
+        r0, r1 = ks.relinearize(d0, d1, d2, eng.upload(evk))                  # addends on both parts
+        v0, v1 = keyswitch_ref(c, evk, qs, L, K, dnum, logn, add0=add, add1=c)
+        assert (r0.download() == v0).all() and (r1.download() == v1).all()
+    finally:
+        eng.set_option("ks_fused", -1)
+    eng.check()
+
+
+@pytest.mark.parametrize("bits", [50, 61])
+def test_wide_tile_geometry_of_the_2_16_transform(F, eng, bits):
+    """"tile_geo" 0 (the widest column tile, kept for 2^16 tuning runs) gives the same words as the default geometry."""
+    from oracle import cport as O
+    logn, N, n_poly = 16, 1 << 16, 2
+    qs = F.create_moduli(N, [bits])
+    t = eng.tables(logn, qs)
+    rng = np.random.default_rng(bits)
+    data = rng.integers(0, qs[0], (n_poly, 1, N), dtype=np.uint64)
+    eng.set_option("tile_geo", 0)
+    try:
+        d = eng.upload(data)
+        t.forward(d, n_poly=n_poly)
+        got = d.download().reshape(data.shape)
+        rp = O.root_powers(qs[0], logn)
+        for p in range(n_poly):
+            assert (got[p, 0] == O.nwt_forward(data[p, 0], qs[0], rp)).all()
+        t.inverse(d, n_poly=n_poly)
+        assert (d.download().reshape(data.shape) == data).all()
+    finally:
+        eng.set_option("tile_geo", 1)
+    eng.check()
