@@ -266,3 +266,36 @@ def test_the_two_launches_one_at_a_time(F, eng, O, logn, bits, nt):
         eng.set_option("ntt_only_pass", -1)
         eng.set_option("ntt_stream", -1)
     eng.check()
+
+
+@pytest.mark.parametrize("split", [1, 0])
+def test_two_caller_streams_free_running(F, eng, split):
+    """Two caller streams transform their halves of a 528 MiB mixed-path batch forward and back, call after call with no
+    synchronisation in between (each with its own side stream and scratch when the split is on): the round trips return the input
+    word for word -- no piece reads a scratch another piece still owns."""
+    import torch
+    from fhe_reliability_gpu_amd._lib import check, lib
+    N, polys = 1 << 16, 352
+    qs = F.create_moduli(N, [50, 61, 50])
+    t = eng.tables(16, qs)
+    g = torch.Generator(device="cuda")
+    g.manual_seed(11)
+    data = torch.empty((polys, 3, N), dtype=torch.int64, device="cuda")
+    for l, q in enumerate(qs):
+        data[:, l, :] = torch.randint(0, q, (polys, N), generator=g, device="cuda", dtype=torch.int64)
+    ref = data.clone()
+    streams = [torch.cuda.Stream(), torch.cuda.Stream()]
+    half = polys // 2
+    torch.cuda.synchronize()
+    eng.set_option("ntt_split", split)
+    try:
+        for _ in range(8):
+            for i, s in enumerate(streams):
+                ptr, sp = C.c_void_p(data.data_ptr() + i * half * 3 * N * 8), C.c_void_p(s.cuda_stream)
+                check(lib.fhe_ntt_forward_batch(eng._h, ptr, t._h, half, 3, 0, sp))
+                check(lib.fhe_ntt_inverse_batch(eng._h, ptr, t._h, half, 3, 0, sp))
+        torch.cuda.synchronize()
+    finally:
+        eng.set_option("ntt_split", -1)
+    assert torch.equal(data, ref)
+    eng.check()
