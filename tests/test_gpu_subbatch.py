@@ -270,13 +270,13 @@ def test_the_two_launches_one_at_a_time(F, eng, O, logn, bits, nt):
 
 @pytest.mark.parametrize("split", [1, 0])
 def test_two_caller_streams_free_running(F, eng, split):
-    """Two caller streams transform their halves of a 528 MiB mixed-path batch forward and back, call after call with no
+    """Two caller streams transform their halves of a 1.2 GiB mixed-path batch forward and back, call after call with no
     synchronisation in between (each with its own side stream and scratch when the split is on): the round trips return the input
     word for word -- no piece reads a scratch another piece still owns."""
     import torch
     from fhe_reliability_gpu_amd._lib import check, lib
-    N, polys = 1 << 16, 352
-    qs = F.create_moduli(N, [50, 61, 50])
+    N, polys = 1 << 16, 800               # per call: a 400 MiB run of two FP64 limbs and a 200 MiB run of one 61-bit limb, both cut
+    qs = F.create_moduli(N, [50, 50, 61])
     t = eng.tables(16, qs)
     g = torch.Generator(device="cuda")
     g.manual_seed(11)
@@ -289,7 +289,7 @@ def test_two_caller_streams_free_running(F, eng, split):
     torch.cuda.synchronize()
     eng.set_option("ntt_split", split)
     try:
-        for _ in range(8):
+        for _ in range(4):
             for i, s in enumerate(streams):
                 ptr, sp = C.c_void_p(data.data_ptr() + i * half * 3 * N * 8), C.c_void_p(s.cuda_stream)
                 check(lib.fhe_ntt_forward_batch(eng._h, ptr, t._h, half, 3, 0, sp))
