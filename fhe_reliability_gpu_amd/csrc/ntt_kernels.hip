@@ -368,7 +368,8 @@ struct ChecksumTap {
             if constexpr (A::PATH == PATH_F64) {
                 // generate_weights (negaclic_ntt.py:7-13) computed in place of a table read: small integers
                 const u32 i = pos0 + idx;
-                const double w = (double)((i & ((1u << logp) - 1u)) + (i >> logp) + 2u);
+                // (the small integer becomes a double through the exponent trick of from_canonical: one subtraction, no v_cvt_f64_u32)
+                const double w = ArithF64::from_canonical((u64)((i & ((1u << logp) - 1u)) + (i >> logp) + 2u));
                 A::lazy_acc(acc_in, A::mulmod_w(x, w, w * c.ninv, c), ++n_in, c);
             } else {
                 A::lazy_acc(acc_in, A::mulmod(x, win[idx], c), ++n_in, c);
@@ -422,7 +423,7 @@ struct PhaseTap {
         if constexpr (PASS == 0) {
             if constexpr (A::PATH == PATH_F64) {
                 const u32 i = pos0 + idx;
-                const double w = (double)((i & ((1u << logp) - 1u)) + (i >> logp) + 2u);     // generate_weights, negaclic_ntt.py:7-13
+                const double w = ArithF64::from_canonical((u64)((i & ((1u << logp) - 1u)) + (i >> logp) + 2u));     // generate_weights, negaclic_ntt.py:7-13
                 A::lazy_acc(acc_a, A::mulmod_w(x, w, w * c.ninv, c), ++n_a, c);
             } else {
                 A::lazy_acc(acc_a, A::mulmod(x, win[idx], c), ++n_a, c);
@@ -838,11 +839,11 @@ struct SubScaleTap {
         const typename ArithF64::Ctx c{n, ninv, q};
         double xv = ArithF64::from_canonical(x);
         if (pre) {
-            const double pw = (double)pre;
+            const double pw = ArithF64::from_canonical(pre);          // residues below 2^50: exact, and no conversion instruction
             xv = ArithF64::mulmod_w(xv, pw, pw * ninv, c);              // |.| < 0.9 q
         }
         const double d = ArithF64::from_canonical(a) - xv;             // |d| < 1.9 q
-        const double sw = (double)scal;
+        const double sw = ArithF64::from_canonical(scal);
         double v = ArithF64::mulmod_w(d, sw, sw * ninv, c);            // |v| < 0.9 q
         if (has_add) v += ArithF64::from_canonical(t);
         return ArithF64::canonical(v, c);
