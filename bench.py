@@ -444,9 +444,15 @@ def main():
                 else:
                     call = lambda: check(lib.fhe_keyswitch_apply(eng._h, ks._h, P(o0), P(o1), P(c0), P(evk), sptr))
                     words = L + key_words + 2 * L
-                for _ in range(3):
-                    call()
-                torch.cuda.synchronize()
+                # warm for 60 ms of wall time (the set-up above leaves the device idle long enough for its clocks to drop), then
+                # time at least `reps` calls and at least ~120 ms of them
+                tw, done_calls = time.perf_counter(), 0
+                while time.perf_counter() - tw < 0.06:
+                    for _ in range(5):
+                        call()
+                    torch.cuda.synchronize()
+                    done_calls += 5
+                reps = max(reps, int(0.12 / ((time.perf_counter() - tw) / done_calls)))
                 e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
                 tw = time.perf_counter()
                 e0.record(stream)
@@ -533,7 +539,7 @@ def main():
             # broadcast per rescale (dist.sharded_rotate / sharded_hmult).  Total work is fixed as the rank count grows; per call:
             # the compute phases and the joins from CUDA events on this rank's stream, max over ranks.
             from fhe_reliability_gpu_amd.dist import ShardedKeySwitch, ks_layout, sharded_hmult, sharded_rotate
-            logn, L, K, dnum, reps = (16, 44, 11, 4, 20) if kind == "rotate" else (17, 32, 8, 4, 10)
+            logn, L, K, dnum, reps = (16, 44, 11, 4, 60) if kind == "rotate" else (17, 32, 8, 4, 40)
             n = 1 << logn
             qk = F.create_moduli(n, [args.bits] * (L + K))
             tk = eng.tables(logn, qk)
@@ -562,7 +568,7 @@ def main():
             else:
                 call = lambda tm=None: sharded_hmult(plan, c0, c1, b0, b1, gk, rescale=True, timings=tm)
             with torch.cuda.stream(stream):
-                for _ in range(3):
+                for _ in range(30):      # (a fixed count: every rank must issue the same collectives; enough to bring the clocks back up)
                     call()
                 barrier()
                 tm = {}
