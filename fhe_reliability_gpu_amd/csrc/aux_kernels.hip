@@ -4,6 +4,8 @@
 // coefficient column) per lane, 64-bit coalesced accesses along N.
 #include "ntt_launch.hpp"
 
+#include <cstdlib>
+
 namespace fhe {
 
 __device__ __forceinline__ u64 mulmod_b(u64 a, u64 b, u64 q, u64 r0, u64 r1)
@@ -194,6 +196,30 @@ constexpr int BC_MAX_LIMBS = 64;
 struct BcF64 {
     typedef double acc_t;
     static __device__ __forceinline__ double load(u64 raw, u64 q) { return ArithF64::from_canonical(raw < q ? raw : reduce_any_u64(raw, q)); }
+    // the same without a function call (a call site makes every live register of an unrolled kernel a spill candidate): words
+    // outside [0, q) -- any 64-bit pattern -- are folded in exact FP64 arithmetic, hi * (2^32 mod q) + lo; result lazy, |.| <= q/2 + 1
+    static __device__ __forceinline__ bool out_of_range(u64 raw, u64 q) { return raw >= q; }
+    static __device__ __forceinline__ double from_word(u64 raw) { return ArithF64::from_canonical(raw); }
+    // any 64-bit word -> canonical residue, exact FP64 arithmetic, no call
+    static __device__ __forceinline__ u64 fold(u64 raw, u64 q, const ArithF64::Ctx &c)
+    {
+        if (raw < q) return raw;
+        double hi = (double)(u32)(raw >> 32), lo = (double)(u32)raw, w = 4294967296.0;
+        ArithF64::reduce(hi, c);
+        ArithF64::reduce(w, c);
+        double r = ArithF64::mulmod_w(hi, w, w * c.ninv, c) + lo;
+        return ArithF64::canonical(r, c);
+    }
+    static __device__ __forceinline__ double load_inline(u64 raw, u64 q, const ArithF64::Ctx &c)
+    {
+        if (__builtin_expect(raw < q, 1)) return ArithF64::from_canonical(raw);
+        double hi = (double)(u32)(raw >> 32), lo = (double)(u32)raw, w = 4294967296.0;
+        ArithF64::reduce(hi, c);
+        ArithF64::reduce(w, c);
+        double r = ArithF64::mulmod_w(hi, w, w * c.ninv, c) + lo;
+        ArithF64::reduce(r, c);
+        return r;
+    }
     static __device__ __forceinline__ ArithF64::Ctx ctx(u64 q, const Tw &fp) { return ArithF64::Ctx{u64_bits_to_double(fp.a), u64_bits_to_double(fp.b), q}; }
     static __device__ __forceinline__ double mul(double a, const Tw &t, const ArithF64::Ctx &c) { return ArithF64::mulmod(a, t, c); }
     static __device__ __forceinline__ double sub(double a, double b, const ArithF64::Ctx &) { return a - b; }
@@ -216,6 +242,10 @@ struct BcU64 {
         u64 q;
     };
     static __device__ __forceinline__ u64 load(u64 raw, u64) { return raw; }   // the Shoup product takes any 64-bit word
+    static __device__ __forceinline__ u64 load_inline(u64 raw, u64, const Ctx &) { return raw; }
+    static __device__ __forceinline__ bool out_of_range(u64, u64) { return false; }
+    static __device__ __forceinline__ u64 from_word(u64 raw) { return raw; }
+    static __device__ __forceinline__ u64 fold(u64 raw, u64, const Ctx &) { return raw; }
     static __device__ __forceinline__ Ctx ctx(u64 q, const Tw &) { return Ctx{q}; }
     static __device__ __forceinline__ u64 mul(u64 a, const Tw &t, const Ctx &c) { return mulmod_shoup(a, t.a, t.b, c.q); }
     static __device__ __forceinline__ u64 sub(u64 a, u64 b, const Ctx &c) { return a >= b ? a - b : a + c.q - b; }
@@ -304,6 +334,173 @@ __device__ __forceinline__ void bc_exact_body(const BcJob &job, u64 N, u32 oc)
     }
 }
 
+// ---------------------------------------------------------------------------
+// Bases of up to 16 limbs (every key-switch digit, every mod-down): the same arithmetic with the number of input limbs a
+// compile-time constant, so that the whole conversion of a coefficient is straight-line code -- no branch per product, every
+// constant's LDS read issued ahead of its use, OU outputs (x CPT coefficients) accumulated side by side.  The runtime-m body
+// above compiled to one basic block per product (ds_read, wait, seven dependent FP64 instructions, branch): 40 % of the
+// vector issue rate at N = 2^16, L = 44, alpha = 11 (51 us per launch).  Constants: the digit table and this workgroup's
+// slice of the output table are staged in LDS once per workgroup ([output][limb], one limb's 16 bytes after the other).
+// ---------------------------------------------------------------------------
+// nothing moves across: neither in the optimiser (the memory clobber) nor in the instruction scheduler
+__device__ __forceinline__ void bc_sched_fence()
+{
+    __asm__ volatile("" ::: "memory");
+    __builtin_amdgcn_sched_barrier(0);
+}
+// the constants in LDS are invariant in the coefficient loop: without this the compiler hoists every read out of it (hundreds of registers)
+__device__ __forceinline__ void bc_no_hoist() { __asm__ volatile("" ::: "memory"); }
+
+template <int M, class B, int CPT, int OU>
+__device__ __forceinline__ void bc_exact_fixed(const BcJob &job, u64 N, u32 oc)
+{
+    typedef typename B::acc_t T;
+    constexpr int OCMAX = 64;
+    __shared__ Tw s_dig[M * M], s_hor[M * OCMAX], s_fpi[M], s_fpo[OCMAX];
+    __shared__ u64 s_pi[M], s_qo[OCMAX];
+    const BaseConvPlanDev &pl = job.pl;
+    const u64 *__restrict__ in = job.in;
+    u64 *__restrict__ out = job.out;
+    const int k = pl.k;
+    const u32 FHE_CONSTANT *rows = (const u32 FHE_CONSTANT *)(__UINTPTR_TYPE__)job.in_rows;
+    const Tw FHE_CONSTANT *dig = (const Tw FHE_CONSTANT *)(__UINTPTR_TYPE__)pl.dig, *hor = (const Tw FHE_CONSTANT *)(__UINTPTR_TYPE__)pl.hor;
+    const Tw FHE_CONSTANT *fp_in = (const Tw FHE_CONSTANT *)(__UINTPTR_TYPE__)pl.fp_in, *fp_out = (const Tw FHE_CONSTANT *)(__UINTPTR_TYPE__)pl.fp_out;
+    const u64 FHE_CONSTANT *mod_in = (const u64 FHE_CONSTANT *)(__UINTPTR_TYPE__)pl.mod_in, *mod_out = (const u64 FHE_CONSTANT *)(__UINTPTR_TYPE__)pl.mod_out;
+    const int o0 = (int)blockIdx.y * (int)oc, o1 = o0 + (int)oc < k ? o0 + (int)oc : k, cnt = o1 - o0;
+    if (cnt <= 0) return;
+    for (int t = threadIdx.x; t < M * M; t += blockDim.x) s_dig[t] = dig[t];                                    // [l][j]
+    for (int t = threadIdx.x; t < M * cnt; t += blockDim.x) s_hor[t] = hor[(t % M) * k + o0 + t / M];          // [o - o0][l]
+    for (int t = threadIdx.x; t < M; t += blockDim.x) {
+        s_fpi[t] = fp_in[t];
+        s_pi[t] = mod_in[t];
+    }
+    for (int t = threadIdx.x; t < cnt; t += blockDim.x) {
+        s_fpo[t] = fp_out[o0 + t];
+        s_qo[t] = mod_out[o0 + t];
+    }
+    __syncthreads();
+    u64 roff[M];      // word offset of input limb j (uniform)
+#pragma unroll
+    for (int j = 0; j < M; j++) roff[j] = (rows ? (u64)rows[j] : (u64)j) * N;
+    for (u64 i = (blockIdx.x * (u64)blockDim.x + threadIdx.x) * CPT; i < N; i += (u64)gridDim.x * blockDim.x * CPT) {
+        bc_no_hoist();
+        u64 raw[M][CPT];
+#pragma unroll
+        for (int j = 0; j < M; j++) {
+            const u64 *src = in + roff[j] + i;
+            if constexpr (CPT == 2) {
+                const ulonglong2 v = *reinterpret_cast<const ulonglong2 *>(src);
+                raw[j][0] = v.x;
+                raw[j][1] = v.y;
+            } else {
+                raw[j][0] = *src;
+            }
+        }
+        // words outside [0, q) (the fault-injection harnesses feed them): ONE cold branch for the whole coefficient
+        T x[M][CPT];
+        bool bad = false;
+#pragma unroll
+        for (int j = 0; j < M; j++) {
+#pragma unroll
+            for (int e = 0; e < CPT; e++) bad |= B::out_of_range(raw[j][e], s_pi[j]);
+        }
+        if (__builtin_expect(bad, 0)) {
+#pragma unroll
+            for (int j = 0; j < M; j++) {
+                const auto cx = B::ctx(s_pi[j], s_fpi[j]);
+#pragma unroll
+                for (int e = 0; e < CPT; e++) raw[j][e] = B::fold(raw[j][e], s_pi[j], cx);
+            }
+        }
+#pragma unroll
+        for (int j = 0; j < M; j++) {
+#pragma unroll
+            for (int e = 0; e < CPT; e++) x[j][e] = B::from_word(raw[j][e]);
+        }
+        bc_sched_fence();
+        // (the fences bound how far ahead the constants' LDS reads are issued: left alone the compiler issues all of them first and
+        // spills hundreds of registers)
+        T c[M][CPT];
+#pragma unroll
+        for (int j = 0; j < M; j++) {
+            const u64 pj = s_pi[j];
+            const auto cx = B::ctx(pj, s_fpi[j]);
+            const Tw a = s_dig[j * M + j];
+            T t[CPT];
+#pragma unroll
+            for (int e = 0; e < CPT; e++) t[e] = B::mul(x[j][e], a, cx);
+#pragma unroll
+            for (int l = 0; l < j; l++) {
+                const Tw w = s_dig[l * M + j];
+#pragma unroll
+                for (int e = 0; e < CPT; e++) {
+                    t[e] = B::sub(t[e], B::mul(c[l][e], w, cx), cx);
+                    B::relax(t[e], l + 1, cx);
+                }
+                if ((l & 3) == 3) bc_sched_fence();
+            }
+#pragma unroll
+            for (int e = 0; e < CPT; e++) c[j][e] = B::digit(t[e], cx);
+            bc_sched_fence();
+        }
+#pragma unroll 1
+        for (int ob = 0; ob < cnt; ob += OU) {
+            bc_no_hoist();
+            T acc[OU][CPT];
+            int oo[OU];
+#pragma unroll
+            for (int u = 0; u < OU; u++) oo[u] = ob + u < cnt ? ob + u : cnt - 1;     // the block's tail recomputes the last output (no branch)
+            Tw w[2][OU];
+            decltype(B::ctx(0, Tw{})) cxu[OU];
+#pragma unroll
+            for (int u = 0; u < OU; u++) {
+                w[0][u] = s_hor[oo[u] * M];
+                cxu[u] = B::ctx(s_qo[oo[u]], s_fpo[oo[u]]);
+            }
+#pragma unroll
+            for (int l = 0; l < M; l++) {
+                if (l + 1 < M) {
+#pragma unroll
+                    for (int u = 0; u < OU; u++) w[(l + 1) & 1][u] = s_hor[oo[u] * M + l + 1];      // next limb's constants: in flight under this limb's products
+                }
+#pragma unroll
+                for (int u = 0; u < OU; u++) {
+#pragma unroll
+                    for (int e = 0; e < CPT; e++) {
+                        if (l == 0) acc[u][e] = B::mul(c[0][e], w[0][u], cxu[u]);
+                        else {
+                            acc[u][e] = B::add(acc[u][e], B::mul(c[l][e], w[l & 1][u], cxu[u]), cxu[u]);
+                            B::relax(acc[u][e], l, cxu[u]);
+                        }
+                    }
+                }
+                bc_sched_fence();
+            }
+            // (unconditional stores: a block's tail writes its last output again -- same thread, same value -- instead of branching,
+            // which would let the compiler sink each output's arithmetic into its own conditional block)
+#pragma unroll
+            for (int u = 0; u < OU; u++) {
+                const int o = o0 + oo[u];
+                u64 *dst = out + (u64)((u32)o < job.gap_at ? o : o + job.gap) * N + i;
+                if constexpr (CPT == 2) *reinterpret_cast<ulonglong2 *>(dst) = ulonglong2{B::out(acc[u][0], cxu[u]), B::out(acc[u][1], cxu[u])};
+                else *dst = B::out(acc[u][0], cxu[u]);
+            }
+        }
+    }
+}
+
+template <int M, class B, int CPT, int OU>
+__global__ __launch_bounds__(256, 4) void k_bc_exact_fixed(const BcJob *jobs, BcJob one, u64 N, u32 oc)
+{
+    if (jobs) {
+        const BcJob job = jobs[blockIdx.z];
+        if (job.pl.m != M) return;              // a job list may mix digit sizes (the last digit of a key switch can be shorter): one launch per size
+        bc_exact_fixed<M, B, CPT, OU>(job, N, oc);
+    } else {
+        bc_exact_fixed<M, B, CPT, OU>(one, N, oc);
+    }
+}
+
 // one conversion, job passed by value
 template <int MAXM, class B, bool STAGE>
 __global__ __launch_bounds__(256) void k_baseconv_exact(BcJob job, u64 N, u32 oc)
@@ -339,38 +536,94 @@ static void launch_exact(hipStream_t st, dim3 grid, const BcJob *dev_jobs, const
 #undef FHE_BC
 }
 
-// aim at >= 2048 workgroups: slice the k outputs over blockIdx.y while a slice stays at least as large as the
+// aim at >= `target` workgroups: slice the k outputs over blockIdx.y while a slice stays at least as large as the
 // digit computation it repeats (m/2 products per digit on average)
-static u32 bc_slices(u32 gx, u32 jobs, int m, int k)
+static u32 bc_slices(u32 gx, u32 jobs, int m, int k, u32 target = 2048)
 {
     u32 slices = 1;
-    while (gx * jobs * slices < 2048 && slices * 2 <= (u32)k && (u32)k / (slices * 2) >= (u32)(m + 1) / 2) slices *= 2;
+    while (gx * jobs * slices < target && slices * 2 <= (u32)k && (u32)k / (slices * 2) >= (u32)(m + 1) / 2) slices *= 2;
     return slices;
+}
+
+// tuning knobs of the fixed-size form (read once): FHE_BC_VARIANT = CPT * 10 + OU (0 = the runtime-m kernels), FHE_BC_WGS = workgroups to aim at
+static int bc_env(const char *name, int dflt)
+{
+    const char *v = getenv(name);
+    return v ? atoi(v) : dflt;
+}
+
+template <class B, int CPT, int OU>
+static void launch_fixed_m(hipStream_t st, dim3 grid, const BcJob *dev_jobs, const BcJob &job, int m, u64 N, u32 oc)
+{
+    switch (m) {
+#define FHE_BCM(MM) case MM: hipLaunchKernelGGL((k_bc_exact_fixed<MM, B, CPT, OU>), grid, dim3(256), 0, st, dev_jobs, job, N, oc); break;
+        FHE_BCM(1) FHE_BCM(2) FHE_BCM(3) FHE_BCM(4) FHE_BCM(5) FHE_BCM(6) FHE_BCM(7) FHE_BCM(8)
+        FHE_BCM(9) FHE_BCM(10) FHE_BCM(11) FHE_BCM(12) FHE_BCM(13) FHE_BCM(14) FHE_BCM(15) FHE_BCM(16)
+#undef FHE_BCM
+    default: break;
+    }
+}
+
+// m_mask: bit (m - 1) set for every input size present among the jobs (one launch per size; a launch's workgroups of the other
+// sizes leave at once)
+template <class B>
+static void launch_fixed(hipStream_t st, const BcJob *dev_jobs, const BcJob &job, u32 n_jobs, u32 m_mask, int max_k, u64 N)
+{
+    static const int variant = bc_env("FHE_BC_VARIANT", 14), target = bc_env("FHE_BC_WGS", 1024);
+    int cpt = variant / 10, ou = variant % 10;
+    if (N & 1) cpt = 1;
+    for (int m = 1; m <= 16; m++) {
+        if (!((m_mask >> (m - 1)) & 1)) continue;
+        const u64 want = (N / cpt + 255) / 256;
+        const u32 gx = (u32)(want > 16384 ? 16384 : want);
+        const u32 slices = bc_slices(gx, n_jobs, m, max_k, (u32)target), oc = ((u32)max_k + slices - 1) / slices;
+        const dim3 grid(gx, ((u32)max_k + oc - 1) / oc, n_jobs);
+        if (cpt == 2 && ou == 4) launch_fixed_m<B, 2, 4>(st, grid, dev_jobs, job, m, N, oc);
+        else if (cpt == 2) launch_fixed_m<B, 2, 2>(st, grid, dev_jobs, job, m, N, oc);
+        else if (ou == 4) launch_fixed_m<B, 1, 4>(st, grid, dev_jobs, job, m, N, oc);
+        else launch_fixed_m<B, 1, 2>(st, grid, dev_jobs, job, m, N, oc);
+    }
+}
+static bool bc_fixed_on()
+{
+    static const int variant = bc_env("FHE_BC_VARIANT", 14);
+    return variant != 0;
 }
 
 hipError_t launch_baseconv_exact(hipStream_t st, u64 *out, const u64 *in, const BaseConvPlanDev &pl, u64 N, u32 gap_at, u32 gap, const u32 *in_rows)
 {
     if (pl.m > BC_MAX_LIMBS) return hipErrorInvalidValue;
+    const BcJob job{pl, in, out, gap_at, gap, in_rows};
+    if (pl.m <= 16 && bc_fixed_on()) {
+        if (pl.f64) launch_fixed<BcF64>(st, nullptr, job, 1, 1u << (pl.m - 1), pl.k, N);
+        else launch_fixed<BcU64>(st, nullptr, job, 1, 1u << (pl.m - 1), pl.k, N);
+        return hipGetLastError();
+    }
     u64 want = (N + 255) / 256;
     const u32 gx = (u32)(want > 16384 ? 16384 : want);
     const u32 slices = bc_slices(gx, 1, pl.m, pl.k), oc = ((u32)pl.k + slices - 1) / slices;
     const dim3 grid(gx, ((u32)pl.k + oc - 1) / oc);
-    const BcJob job{pl, in, out, gap_at, gap, in_rows};
     if (pl.f64) launch_exact<BcF64>(st, grid, nullptr, job, pl.m, N, oc);
     else launch_exact<BcU64>(st, grid, nullptr, job, pl.m, N, oc);
     return hipGetLastError();
 }
 
-// jobs: device array of n_jobs entries that share the arithmetic path (f64) ; max_m / max_k = largest m / k among them
-hipError_t launch_baseconv_exact_jobs(hipStream_t st, const BcJob *dev_jobs, u32 n_jobs, int max_m, int max_k, bool f64, u64 N)
+// jobs: device array of n_jobs entries that share the arithmetic path (f64) ; max_m / max_k = largest m / k among them;
+// m_mask: bit (m - 1) set for every input size m <= 16 present among the jobs (0 = unknown: the runtime-m kernels)
+hipError_t launch_baseconv_exact_jobs(hipStream_t st, const BcJob *dev_jobs, u32 n_jobs, int max_m, int max_k, bool f64, u64 N, u32 m_mask)
 {
     if (!n_jobs) return hipSuccess;
     if (max_m > BC_MAX_LIMBS || n_jobs > 65535) return hipErrorInvalidValue;
+    const BcJob none{};
+    if (m_mask && max_m <= 16 && bc_fixed_on()) {
+        if (f64) launch_fixed<BcF64>(st, dev_jobs, none, n_jobs, m_mask, max_k, N);
+        else launch_fixed<BcU64>(st, dev_jobs, none, n_jobs, m_mask, max_k, N);
+        return hipGetLastError();
+    }
     u64 want = (N + 255) / 256;
     const u32 gx = (u32)(want > 16384 ? 16384 : want);
     const u32 slices = bc_slices(gx, n_jobs, max_m, max_k), oc = ((u32)max_k + slices - 1) / slices;
     const dim3 grid(gx, ((u32)max_k + oc - 1) / oc, n_jobs);
-    const BcJob none{};
     if (f64) launch_exact<BcF64>(st, grid, dev_jobs, none, max_m, N, oc);
     else launch_exact<BcU64>(st, grid, dev_jobs, none, max_m, N, oc);
     return hipGetLastError();

@@ -67,7 +67,7 @@ static int rescale_finish(fhe_ctx *ctx, fhe_keyswitch *p, uint64_t *const *outs,
     // a rescale converts ONE limb: at the two-launch sizes x mod q_j rides on the column pass of the residues' transform
     const bool trivial = p->log_n >= 13 && !plain;
     if (!trivial) {
-        e = launch_baseconv_exact_jobs(st, p->rs_jobs.as<BcJob>(), (u32)n_parts, 1, (int)R, p->last->dev.f64 != 0, N);
+        e = launch_baseconv_exact_jobs(st, p->rs_jobs.as<BcJob>(), (u32)n_parts, 1, (int)R, p->last->dev.f64 != 0, N, 1u);
         if (e != hipSuccess) return hip_fail(e, "launch_baseconv_exact_jobs");
         if (p->plain_modulus && (rc = fhe_scalar_affine(ctx, delta, delta, p->t_mod_Q.data() + lo, nullptr, t, n_parts, R, lo, st))) return rc;
     }

@@ -172,6 +172,7 @@ struct fhe_keyswitch {
     DevBuf coef, ext, acc, conv, rot;  // coef [L][N] (one device: = g1), ext [dnum][m_own][N], acc [2][m_own][N], conv [2][cn][N]
     DevBuf up_jobs, down_jobs;         // device job lists: all digit extensions / both mod-down conversions in one launch each
     int up_max_m = 0, up_max_k = 0;
+    u32 up_m_mask = 0;                 // bit (m - 1): a digit of m limbs exists (fixed-size conversion kernels, one launch per size)
     bool up_batched = false;           // every digit plan on the same arithmetic path
     DevBuf ext_map[2];                 // per arithmetic path: the limbs of ext the forward transform covers
     u32 ext_units[2] = {0, 0};

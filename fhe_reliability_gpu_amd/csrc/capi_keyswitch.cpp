@@ -148,6 +148,7 @@ static int ks_create(fhe_ctx *ctx, const fhe_ntt_tables *t, int L, int K, int dn
             if (first < 0) first = d;
             up.push_back(BcJob{pl, p->g1, p->ext.as<u64>() + (size_t)d * MO * N, gaps[d].first, gaps[d].second, p->up_rows.as<u32>() + (size_t)d * p->alpha});
             p->up_max_m = std::max(p->up_max_m, pl.m);
+            if (pl.m <= 16) p->up_m_mask |= 1u << (pl.m - 1);
             p->up_max_k = std::max(p->up_max_k, pl.k);
             p->up_batched = p->up_batched && pl.f64 == p->up[first]->dev.f64;
         }
@@ -235,7 +236,7 @@ static int ks_extend_mac(fhe_ctx *ctx, fhe_keyswitch *p, const uint64_t *d_c, co
         if (trivial) {
             // one-limb digits: nothing to launch, the column pass below reads the digit's limb and reduces on the load
         } else if (p->up_batched) {
-            e = launch_baseconv_exact_jobs(st, p->up_jobs.as<BcJob>(), p->n_up_jobs, p->up_max_m, p->up_max_k, p->up_f64, N);
+            e = launch_baseconv_exact_jobs(st, p->up_jobs.as<BcJob>(), p->n_up_jobs, p->up_max_m, p->up_max_k, p->up_f64, N, p->up_max_m <= 16 ? p->up_m_mask : 0u);
             if (e != hipSuccess) return hip_fail(e, "launch_baseconv_exact_jobs");
         } else {
             for (const BcJob &j : p->up_host) {
@@ -319,7 +320,7 @@ static int ks_finish(fhe_ctx *ctx, fhe_keyswitch *p, uint64_t *d_out0, uint64_t 
     // one special prime at a two-launch size: the conversion x mod q_j rides on the converted limbs' column pass
     const bool trivial = p->K == 1 && p->log_n >= 13 && !plain;
     if (!trivial) {
-        e = launch_baseconv_exact_jobs(st, p->down_jobs.as<BcJob>(), 2, p->down->dev.m, p->down->dev.k, p->down->dev.f64 != 0, N);
+        e = launch_baseconv_exact_jobs(st, p->down_jobs.as<BcJob>(), 2, p->down->dev.m, p->down->dev.k, p->down->dev.f64 != 0, N, p->down->dev.m <= 16 ? 1u << (p->down->dev.m - 1) : 0u);
         if (e != hipSuccess) return hip_fail(e, "launch_baseconv_exact_jobs");
         if (p->plain_modulus && (rc = fhe_scalar_affine(ctx, conv, conv, p->t_mod_Q.data() + sh.clo, nullptr, t, 2, sh.cn, sh.clo, st))) return rc;
     }

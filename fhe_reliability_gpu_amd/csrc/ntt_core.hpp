@@ -66,11 +66,32 @@ FHE_HD constexpr u32 tw_index(int sblk, int sigma, u32 i)
                         : (((1u << (sigma - sblk)) + (i & ((1u << (sigma - sblk)) - 1u))) << sblk) + (i >> (sigma - sblk));
 }
 
+// Where a register step takes its twiddles from.  The default source is the limb's table in global memory (TwPtr); a row pass that
+// runs several transforms of ONE limb on the same rows (the key switch's fused inner product: every digit's extension of a limb) can
+// instead keep the rows' factors in LDS, 8 bytes each, and form the quotient w/q as w * (1/q) on the fly (RowTwLds): the factors then
+// cross the fabric once per workgroup instead of once per transform -- they weigh twice what the data does (16 bytes per point).
+template <int SBLK> FHE_D Tw tw_get(TwPtr tw, int sigma, u32 i) { return tw[tw_index(SBLK, sigma, i)]; }
+struct RowTwLds {
+    const double *w;   // [rows of the tile][2^P - 1]: row-major, inside a row stage after stage (stage S0 + t at offset 2^t - 1, block j)
+    double ninv;       // 1 / q
+    u32 row0;          // first row of the tile
+    int s0, per_row;   // S0 (first stage of the row pass), 2^P - 1
+};
+// (the quotient estimate w * ninv is within 1.5 ulp of w/q instead of 0.5: a product's magnitude bound grows from (0.5 + B/4) q to
+// (0.5 + 3B/8) q for an input of magnitude B q -- passes that use this source reduce every fourth stage)
+template <int SBLK> FHE_D Tw tw_get(const RowTwLds &t, int sigma, u32 i)
+{
+    const int tt = sigma - t.s0;
+    const u32 row = (i >> tt) - t.row0, j = i & ((1u << tt) - 1u);
+    const double w = t.w[row * (u32)t.per_row + ((1u << tt) - 1u) + j];
+    return Tw{double_to_u64_bits(w), double_to_u64_bits(w * t.ninv)};
+}
+
 // K forward stages on R = 2^K registers.  Register r holds the point whose K-bit
 // field (most significant bit = first stage) equals r.  `s` = global index of the
 // first stage, `prefix` = value of the s index bits above the field.
-template <class A, int K, u32 RED, int U0, int SBLK>
-FHE_D void radix_fwd(typename A::elem (&x)[1 << K], TwPtr tw, int s, u32 prefix, const typename A::Ctx &c)
+template <class A, int K, u32 RED, int U0, int SBLK, class TWS = TwPtr>
+FHE_D void radix_fwd(typename A::elem (&x)[1 << K], const TWS &tw, int s, u32 prefix, const typename A::Ctx &c)
 {
     constexpr int R = 1 << K;
 #pragma unroll
@@ -82,7 +103,7 @@ FHE_D void radix_fwd(typename A::elem (&x)[1 << K], TwPtr tw, int s, u32 prefix,
         const int half = R >> (u + 1);
 #pragma unroll
         for (int b = 0; b < (1 << u); b++) {
-            const Tw w = tw[tw_index(SBLK, s + u, (prefix << u) + b)];
+            const Tw w = tw_get<SBLK>(tw, s + u, (prefix << u) + b);
 #pragma unroll
             for (int j = 0; j < half; j++) A::bfly_fwd(x[b * 2 * half + j], x[b * 2 * half + j + half], w, c);
         }
@@ -469,8 +490,8 @@ struct RowPass {
     // `base` = first element of the tile's first row; `row0` = index of that row in the limb.  (ROWMODE 1: `base` = the
     // LIMB's first element -- the tile's rows are not adjacent -- and `src` = the natural-order source limb.)
     // `src` (optional, ROWMODE 0): the loading step reads the tile from there instead of `base` -- out-of-place first launch.
-    template <int E, class TAP = NoTap>
-    static FHE_D void phase(int tid, u64 *__restrict__ base, elem *__restrict__ lds, TwPtr tw, u32 row0,
+    template <int E, class TAP = NoTap, class TWS = TwPtr>
+    static FHE_D void phase(int tid, u64 *__restrict__ base, elem *__restrict__ lds, const TWS &tw, u32 row0,
                             const typename A::Ctx &c, const Tw &inv_n, TAP *tap = nullptr, const u64 *src = nullptr, u32 galois = 0,
                             u64 *galois_copy = nullptr, bool nt_src = false)
     {
@@ -524,7 +545,7 @@ struct RowPass {
                 }
                 const u32 prefix = (net_row(row0, row) << DONE) | a;
                 constexpr bool FOLD = INVERSE && LAST && OUT_MODE == IO_CANONICAL && S0 + DONE == 0;
-                if (INVERSE) radix_inv<A, K, RED, U0, SBLK, FOLD>(x, tw, S0 + DONE, prefix, c, &inv_n);
+                if constexpr (INVERSE) radix_inv<A, K, RED, U0, SBLK, FOLD>(x, tw, S0 + DONE, prefix, c, &inv_n);
                 else radix_fwd<A, K, RED, U0, SBLK>(x, tw, S0 + DONE, prefix, c);
                 if (LAST) {
 #pragma unroll

@@ -674,13 +674,13 @@ struct PolymulArgs {
     u64 *c;         // product (may alias either factor)
 };
 
-template <class FR, int E = 0>
-FHE_D void fwd_steps(int tid, u64 *base, typename FR::elem *lds, TwPtr tw, u32 row0, const typename FR::Arith::Ctx &ctx, const Tw &inv_n)
+template <class FR, int E = 0, class TWS = TwPtr>
+FHE_D void fwd_steps(int tid, u64 *base, typename FR::elem *lds, const TWS &tw, u32 row0, const typename FR::Arith::Ctx &ctx, const Tw &inv_n)
 {
     if constexpr (E < FR::NSTEP) {
         if (E > 0) __syncthreads();
-        FR::template phase<E>(tid, base, lds, tw, row0, ctx, inv_n);
-        fwd_steps<FR, E + 1>(tid, base, lds, tw, row0, ctx, inv_n);
+        FR::template phase<E, NoTap, TWS>(tid, base, lds, tw, row0, ctx, inv_n);
+        fwd_steps<FR, E + 1, TWS>(tid, base, lds, tw, row0, ctx, inv_n);
     }
 }
 template <class IR, int E = 1>
@@ -1052,6 +1052,232 @@ __global__ __launch_bounds__(NTT_THREADS, 2) void k_ks_rowmac(KsMacArgs a)
     }
 }
 
+// ---------------------------------------------------------------------------
+// The fused inner product with the rows' twiddle factors kept in LDS (FP64 limbs, two-launch sizes).  Every digit's extension of a
+// limb runs the SAME row pass on the same rows, and a row pass reads 16 bytes of table per point -- twice its data.  Round 2's kernel
+// fetched them again for every digit (PMC: 65 % of the wave-cycles waiting on memory, 0.27 of the vector issue rate, no LDS pressure).
+// Here a workgroup stages its tile's factors once, 8 bytes each (the quotient w/q is formed as w * (1/q) on the fly, ntt_core.hpp
+// RowTwLds), and runs all the digits from them: 32 KiB of factors next to the 33 KiB image, still two workgroups per CU.
+// The looser quotient estimate costs one more range reduction per pass (every fourth stage, from the pass's first stage on).
+// ---------------------------------------------------------------------------
+template <int LOGN>
+struct RowMacLt {
+    typedef ArithF64 A;
+    typedef MidPasses<A, LOGN, 1> MP;
+    typedef typename MP::PL PL;
+    static constexpr int PR = PL::Row::P, NPTS = 1 << PR, S0 = LOGN - PR, TR = MP::TR;
+    typedef typename std::conditional<PR == 8, Steps<3, 3, 2>, typename PL::Row>::type ST;
+    static constexpr u32 red_every4()
+    {
+        u32 m = 0;
+        for (int u = 0; u < PR; u += 4) m |= 1u << u;
+        return m;
+    }
+    // STAGE_BOTH: the register steps take the tile from the LDS image (the kernel copies it there itself, one digit ahead)
+    typedef RowPass<A, ST, LOGN, TR, NTT_THREADS, false, IO_LAZY, IO_LAZY, red_every4(), MP::SB, 0, false, true> FR;
+    static constexpr int TW_PER_ROW = NPTS - 1, TW_ELEMS = TR * TW_PER_ROW;
+    static constexpr size_t LDS_BYTES = ((size_t)FR::LDS_ELEMS + TW_ELEMS) * 8;
+    static_assert(TR * NPTS == 16 * NTT_THREADS, "sixteen points per thread");
+};
+
+template <class FR, int E, class TWS>
+FHE_D void lt_steps(int tid, typename FR::elem *lds, const TWS &tw, u32 row0, const typename FR::Arith::Ctx &ctx, const Tw &inv_n)
+{
+    if constexpr (E <= FR::NSTEP) {
+        FR::template phase<E, NoTap, TWS>(tid, nullptr, lds, tw, row0, ctx, inv_n);
+        __syncthreads();
+        lt_steps<FR, E + 1, TWS>(tid, lds, tw, row0, ctx, inv_n);
+    }
+}
+
+// Software pipeline of a workgroup (one owned limb x one row tile, all digits): every request to memory is made a whole phase
+// before its words are needed, in one batch, with no branch between the requests --
+//   tile of digit d+1  : requested before digit d's butterflies, copied into the LDS image after digit d's products;
+//   key words of digit d: requested before digit d's butterflies, consumed after them;
+//   twiddle factors    : staged once, sixteen requests per thread in flight together.
+// (Round 2's form asked for a digit's tile, its factors and its key words one after the other, each behind the previous one's
+// arithmetic and a cold-path branch per pair: the three parts of a digit ran back to back, 37 + 30 us of 125.)
+template <int LOGN>
+__global__ __launch_bounds__(NTT_THREADS, 2) void k_ks_rowmac_lt(KsMacArgs a)
+{
+    typedef RowMacLt<LOGN> RM;
+    typedef typename RM::FR FR;
+    typedef ArithF64 A;
+    typedef double elem;
+    typedef u64 u64x2 __attribute__((ext_vector_type(2)));
+    constexpr int PAIRS = FR::TROWS * FR::NPTS / 2;
+    constexpr int PER = PAIRS / NTT_THREADS;
+    static_assert(PER == 8, "sixteen points per thread");
+    extern __shared__ __attribute__((aligned(16))) unsigned char rowmac_lds[];
+    elem *lds = reinterpret_cast<elem *>(rowmac_lds);
+    double *twl = lds + FR::LDS_ELEMS;
+    const u32 jj = blockIdx.x / FR::TILES, tile = blockIdx.x % FR::TILES;
+    const u32 tl = jj < a.cn ? a.clo + jj : jj + a.sp_shift;         // table limb of this row
+    const LimbParams &p = a.lp[tl];
+    if (p.path != PATH_F64) return;                                  // integer-path limbs: launch_ks_rowmac runs k_ks_rowmac for them
+    const A::Ctx ctx = A::make_ctx(p);
+    const Tw inv_n = p.inv_n;
+    const TwPtr tw = as_global(p.fwd);
+    const int tid = threadIdx.x;
+    const u32 row0 = tile * FR::TROWS;
+    const size_t toff = (size_t)row0 * FR::NPTS;                      // tile offset inside a limb
+    // the digit whose own limb this row is (its "extension" is the input c itself: no tile, no transform); dnum = none
+    const u32 own_d = jj < a.cn ? tl / a.alpha : a.dnum;
+    // offsets of this thread's pairs inside a tile (in words) and inside the LDS image (in elements)
+    u32 goff[PER], loff[PER];
+#pragma unroll
+    for (int k = 0; k < PER; k++) {
+        const u32 i = (u32)tid + (u32)k * NTT_THREADS, row = i / (FR::NPTS / 2), g = (i % (FR::NPTS / 2)) * 2;
+        goff[k] = row * FR::NPTS + g;
+        loff[k] = row * FR::ROW_LDS + row_pad(g);
+    }
+    auto tile_of = [&](u32 d) { return a.ext + (((size_t)d * a.M + jj) << LOGN) + toff; };
+    // first tile: in flight under the staging of the factors
+    u64x2 tv[PER];
+    u32 d_tile = own_d == 0 ? 1u : 0u;                                // digit whose tile tv holds (>= dnum: none)
+    if (d_tile < a.dnum) {
+        const u64 *src = tile_of(d_tile);
+#pragma unroll
+        for (int k = 0; k < PER; k++) tv[k] = *reinterpret_cast<const u64x2 *>(src + goff[k]);
+    }
+    // the tile's factors: stage S0 + t, blocks (row0 + r) * 2^t + j, r < TR, j < 2^t.  Lanes run along the table's stored order
+    // (ntt_core.hpp tw_index: natural below stage SBLK, blocked from there on -- 2^NB - 1 runs of RUN consecutive entries, then the
+    // natural stages' RUN - TR entries), so the reads are whole lines; sixteen requests per lane, all made before the first is used.
+    {
+        constexpr int SB = RM::MP::SB, S0 = RM::S0, PR = RM::PR, TR = RM::TR;
+        constexpr int NB = LOGN - SB, NN = PR - NB;                    // blocked / natural stages of the pass
+        constexpr u32 RUN = (u32)TR << NN, BLK = ((1u << NB) - 1u) * RUN, TOTAL = BLK + RUN - TR;
+        static_assert((RUN & (RUN - 1)) == 0 && (TR & (TR - 1)) == 0, "powers of two");
+        constexpr int LOG_RUN = __builtin_ctz(RUN), LOG_TR = __builtin_ctz((u32)TR);
+        double wv[16];
+        u32 dst[16];
+#pragma unroll
+        for (int k = 0; k < 16; k++) {
+            u32 f = (u32)tid + (u32)k * NTT_THREADS;
+            f = f < TOTAL ? f : TOTAL - 1u;                             // (the last sixteen lanes repeat the last entry: no branch)
+            const bool blk = f < BLK;
+            // blocked stages
+            const u32 rr = (f >> LOG_RUN) + 1u, pp = f & (RUN - 1u);
+            const u32 u = 31u - (u32)__builtin_clz(rr | 1u), bb = rr - (1u << u), tb = (u32)NN + u;
+            const u32 p0 = ((u32)row0 << tb) >> u;
+            const u32 ib = ((p0 + pp) << u) | bb, srcb = (((1u << u) + bb) << SB) + p0 + pp;
+            // natural stages: stage t holds TR * 2^t entries
+            const u32 e = f - BLK;
+            const u32 tn = 31u - (u32)__builtin_clz(((e >> LOG_TR) + 1u) | 1u);
+            const u32 in = ((u32)row0 << tn) + (e - (((1u << tn) - 1u) << LOG_TR)), srcn = (1u << (S0 + tn)) + in;
+            const u32 t = blk ? tb : tn, i = blk ? ib : in, src = blk ? srcb : srcn;
+            const u32 r = (i >> t) - row0, j = i & ((1u << t) - 1u);
+            dst[k] = r * RM::TW_PER_ROW + ((1u << t) - 1u) + j;
+            wv[k] = u64_bits_to_double(tw[src].a);
+        }
+#pragma unroll
+        for (int k = 0; k < 16; k++) twl[dst[k]] = wv[k];
+    }
+    const RowTwLds tws{twl, ctx.ninv, row0, RM::S0, RM::TW_PER_ROW};
+    elem s0[PER][2], s1[PER][2];
+#pragma unroll
+    for (int k = 0; k < PER; k++) s0[k][0] = s0[k][1] = s1[k][0] = s1[k][1] = 0.0;
+    int terms = 0;
+    const u64 q = p.q;
+    for (u32 d = 0; d < a.dnum; d++) {
+        const bool own = d == own_d;
+        const u64 *k0 = a.evk + ((((size_t)d * 2) * a.M + jj) << LOGN) + toff, *k1 = k0 + ((size_t)a.M << LOGN);
+        // key words: touched once per call, hundreds of MiB of them -- non-temporal, so that they do not push the tiles out of the caches
+        u64x2 kv0[PER], kv1[PER];
+#pragma unroll
+        for (int k = 0; k < PER; k++) {
+            kv0[k] = __builtin_nontemporal_load(reinterpret_cast<const u64x2 *>(k0 + goff[k]));
+            kv1[k] = __builtin_nontemporal_load(reinterpret_cast<const u64x2 *>(k1 + goff[k]));
+        }
+        elem x[PER][2];
+        if (own) {
+            const u64 *src = a.c + ((size_t)jj << LOGN) + toff;
+            u64x2 cw[PER];
+#pragma unroll
+            for (int k = 0; k < PER; k++) cw[k] = *reinterpret_cast<const u64x2 *>(src + goff[k]);
+            bool bad = false;
+#pragma unroll
+            for (int k = 0; k < PER; k++) bad |= (cw[k].x >= q) | (cw[k].y >= q);
+            if (__builtin_expect(bad, 0)) {
+#pragma unroll
+                for (int k = 0; k < PER; k++) {
+                    cw[k].x = barrett128(cw[k].x, 0, q, p.barrett_lo, p.barrett_hi);
+                    cw[k].y = barrett128(cw[k].y, 0, q, p.barrett_lo, p.barrett_hi);
+                }
+            }
+#pragma unroll
+            for (int k = 0; k < PER; k++) {
+                x[k][0] = A::from_canonical(cw[k].x);
+                x[k][1] = A::from_canonical(cw[k].y);
+            }
+        } else {
+            // tv holds this digit's tile (requested a digit ago): into the image, the next one's request goes out, then the steps
+            __syncthreads();                                         // the previous image's pairs have been read (the factors are staged)
+#pragma unroll
+            for (int k = 0; k < PER; k++) *reinterpret_cast<u64x2 *>(lds + loff[k]) = tv[k];
+            u32 nd = d + 1;
+            nd += nd == own_d ? 1u : 0u;
+            if (nd < a.dnum) {
+                const u64 *src = tile_of(nd);
+#pragma unroll
+                for (int k = 0; k < PER; k++) tv[k] = *reinterpret_cast<const u64x2 *>(src + goff[k]);
+            }
+            __syncthreads();
+            lt_steps<FR, 1, RowTwLds>(tid, lds, tws, row0, ctx, inv_n);
+#pragma unroll
+            for (int k = 0; k < PER; k++) {
+                const double2 v = *reinterpret_cast<const double2 *>(lds + loff[k]);
+                x[k][0] = v.x;
+                x[k][1] = v.y;
+            }
+        }
+        // words outside [0, q) (bit-flipped inputs, reliability_test/dotprod_test.cu:38-61): ONE cold branch per digit
+        {
+            bool bad = false;
+#pragma unroll
+            for (int k = 0; k < PER; k++) bad |= (kv0[k].x >= q) | (kv0[k].y >= q) | (kv1[k].x >= q) | (kv1[k].y >= q);
+            if (__builtin_expect(bad, 0)) {
+#pragma unroll
+                for (int k = 0; k < PER; k++) {
+                    kv0[k].x = barrett128(kv0[k].x, 0, q, p.barrett_lo, p.barrett_hi);
+                    kv0[k].y = barrett128(kv0[k].y, 0, q, p.barrett_lo, p.barrett_hi);
+                    kv1[k].x = barrett128(kv1[k].x, 0, q, p.barrett_lo, p.barrett_hi);
+                    kv1[k].y = barrett128(kv1[k].y, 0, q, p.barrett_lo, p.barrett_hi);
+                }
+            }
+        }
+        ++terms;
+#pragma unroll
+        for (int k = 0; k < PER; k++) {
+            A::lazy_acc(s0[k][0], A::mulvar_lazy(x[k][0], A::from_canonical(kv0[k].x), ctx), terms, ctx);
+            A::lazy_acc(s0[k][1], A::mulvar_lazy(x[k][1], A::from_canonical(kv0[k].y), ctx), terms, ctx);
+            A::lazy_acc(s1[k][0], A::mulvar_lazy(x[k][0], A::from_canonical(kv1[k].x), ctx), terms, ctx);
+            A::lazy_acc(s1[k][1], A::mulvar_lazy(x[k][1], A::from_canonical(kv1[k].y), ctx), terms, ctx);
+        }
+    }
+    u64 *o0 = a.acc + ((size_t)jj << LOGN) + toff, *o1 = o0 + ((size_t)a.M << LOGN);
+#pragma unroll
+    for (int k = 0; k < PER; k++) {
+        *reinterpret_cast<u64x2 *>(o0 + goff[k]) = u64x2{A::canonical(s0[k][0], ctx), A::canonical(s0[k][1], ctx)};
+        *reinterpret_cast<u64x2 *>(o1 + goff[k]) = u64x2{A::canonical(s1[k][0], ctx), A::canonical(s1[k][1], ctx)};
+    }
+}
+
+template <int LOGN>
+static hipError_t launch_rowmac_lt(hipStream_t st, const KsMacArgs &a)
+{
+    typedef RowMacLt<LOGN> RM;
+    static_assert(RM::LDS_BYTES <= 80 * 1024, "two workgroups per CU");
+    static bool raised = false;
+    if (!raised) {
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(&k_ks_rowmac_lt<LOGN>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)RM::LDS_BYTES);
+        if (e != hipSuccess) return e;
+        raised = true;
+    }
+    hipLaunchKernelGGL((k_ks_rowmac_lt<LOGN>), dim3(a.M * RM::FR::TILES), dim3(NTT_THREADS), RM::LDS_BYTES, st, a);
+    return hipSuccess;
+}
+
 bool ks_rowmac_supported(int logn) { return logn >= 5 && logn <= NTT_MAX_LOGN; }
 
 template <class A, int LOGN>
@@ -1059,6 +1285,15 @@ static void launch_rowmac_t(hipStream_t st, const KsMacArgs &a)
 {
     constexpr int GEO = LOGN >= 13 ? 1 : 0;
     typedef typename MidPasses<A, LOGN, GEO>::Fwd FR;
+    // FHE_KS_ROWMAC (read once): 1 (default) = FP64 limbs of the two-launch sizes run the pipelined form with the tile's twiddle
+    // factors in LDS (k_ks_rowmac_lt); 0 = round 2's kernel everywhere
+    static const int variant = getenv("FHE_KS_ROWMAC") ? atoi(getenv("FHE_KS_ROWMAC")) : 1;
+    if constexpr (LOGN >= 13 && A::PATH == PATH_F64) {
+        if (variant) {
+            (void)launch_rowmac_lt<LOGN>(st, a);
+            return;
+        }
+    }
     hipLaunchKernelGGL((k_ks_rowmac<A, LOGN, GEO>), dim3(a.M * FR::TILES), dim3(NTT_THREADS), 0, st, a);
 }
 

@@ -172,7 +172,8 @@ struct BcJob {
     const u32 *in_rows = nullptr;   // optional: input limb j sits at row in_rows[j] of `in` (rows of N words) instead of row j --
                                     // the all-gathered slabs of a sharded key switch are padded per rank
 };
-hipError_t launch_baseconv_exact_jobs(hipStream_t st, const BcJob *dev_jobs, u32 n_jobs, int max_m, int max_k, bool f64, u64 N);
+// m_mask: bit (m - 1) set for every input size m <= 16 among the jobs (one straight-line launch per size); 0 = the runtime-m kernels
+hipError_t launch_baseconv_exact_jobs(hipStream_t st, const BcJob *dev_jobs, u32 n_jobs, int max_m, int max_k, bool f64, u64 N, u32 m_mask = 0);
 // key-switch inner product over all digits and both key halves (aux_kernels.hip k_ks_mac).  Rows are the limbs this
 // rank owns: cn ciphertext limbs (table limbs clo ..) followed by the owned special limbs (table limb = row + sp_shift);
 // one device owns everything: M = L + K, cn = L, clo = 0, sp_shift = 0.
