@@ -75,6 +75,65 @@ def host_cores():
     return n
 
 
+FABRIC_SUSTAINED_GBS = 6000.0     # what the transform passes sustain through the fabric (profiles/r02_bench_kt.txt)
+
+
+def traffic_floor_us(kind, logn, L, K, dnum):
+    """Time the launches of one composite need for their OWN bytes at the rate the NTT passes sustain (6.0 TB/s): every launch's
+    reads + writes in limb-sweeps of N words, summed.  Key switch (capi_keyswitch.cpp): opening INTT (two launches, in + out each),
+    digit extension, the extended limbs' column pass, the fused row pass + inner product (extended limbs, own limbs, key, two sums),
+    INTT of the special limbs, mod-down conversion, its column pass, the row pass with the tail (converted limbs, sums, addends, result)."""
+    M, two = L + K, (2 if logn >= 13 else 1)        # two-launch sizes sweep a transform's limbs twice
+    ext = dnum * M - L                              # extended limbs of all digits (a digit's own limbs are not extended)
+    sweeps = 2 * two * L                            # opening INTT
+    sweeps += L + ext                               # digit extension: reads the input, writes the extended limbs
+    sweeps += (2 * ext if two == 2 else 0)          # column pass of the extended limbs
+    sweeps += ext + L + 2 * dnum * M + 2 * M        # row pass + inner product
+    sweeps += 2 * two * 2 * K                       # INTT of the special limbs, both halves
+    sweeps += 2 * K + 2 * L                         # mod-down conversion
+    sweeps += (2 * 2 * L if two == 2 else 0)        # column pass of the converted limbs
+    addends = L if kind == "rotate" else 2 * L if kind == "hmult" else 0
+    sweeps += 2 * L + 2 * L + addends + 2 * L       # row pass with the tail
+    if kind == "rotate":
+        sweeps += L                                 # sigma(c1) kept for the inner product
+    if kind == "hmult":
+        sweeps += 7 * L                             # tensor product: four operands in, three parts out
+        R = L - 1
+        sweeps += 2 * two * 2                       # INTT of the two last limbs
+        sweeps += (2 + 2 * R if two == 2 else 0)    # column pass of the residues (reads the broadcast limbs)
+        sweeps += 2 * R + 2 * R + 2 * R             # row pass with (c - delta) / q_last
+    return sweeps * (8 << logn) / (FABRIC_SUSTAINED_GBS * 1e9) * 1e6
+
+
+def launcher_command(n_gpus, argv, port):
+    """The command a plain `python bench.py --gpus N` turns itself into (the driver's own form of the N > 1 launch)."""
+    return [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={n_gpus}", "--master-addr", "127.0.0.1",
+            "--master-port", str(port), os.path.abspath(__file__)] + list(argv)
+
+
+def self_launch(n_gpus, argv):
+    import socket
+    import subprocess
+    with socket.socket() as sk:                    # a free port for the rendezvous
+        sk.bind(("127.0.0.1", 0))
+        port = sk.getsockname()[1]
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    env.setdefault("MASTER_ADDR", "127.0.0.1")
+    proc = subprocess.Popen(launcher_command(n_gpus, argv, port), env=env, stdout=subprocess.PIPE, text=True)
+    line = None
+    for out in proc.stdout:                        # relay: the ranks' stdout passes through, the JSON line is the last one that parses
+        sys.stdout.write(out)
+        sys.stdout.flush()
+        if out.lstrip().startswith("{"):
+            line = out
+    rc = proc.wait()
+    if rc == 0 and line is None:
+        print("bench.py: the ranks exited cleanly but printed no JSON line", file=sys.stderr)
+        return 3
+    return rc
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -93,11 +152,26 @@ def main():
                     help="HIP streams the batch's polynomials are sharded over inside one GPU (each step = one call per stream)")
     args = ap.parse_args()
 
-    import torch
-
+    # ---- N > 1 started as a plain `python bench.py --gpus N`: become the launcher.  Nothing has touched the GPU yet (torch is not
+    # even imported), so the ranks are CHILD processes of torch.distributed.run; their one JSON line is relayed and their status
+    # becomes ours.  Started under the launcher already (WORLD_SIZE set), the world must be the one that was asked for.
+    if "WORLD_SIZE" not in os.environ:
+        if args.gpus > 1:
+            sys.exit(self_launch(args.gpus, sys.argv[1:]))
+    elif int(os.environ["WORLD_SIZE"]) != args.gpus:
+        print(f"bench.py: --gpus {args.gpus} but WORLD_SIZE={os.environ['WORLD_SIZE']}: refusing to report a line for another world size", file=sys.stderr)
+        sys.exit(2)
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if os.environ.get("FHE_BENCH_DRYRUN"):
+        # launcher rehearsal (tests/test_bench_launcher.py, no GPU): every rank reports in, rank 0 prints the line's skeleton
+        if rank == 0:
+            print(json.dumps({"metric": "dry run of the launcher", "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "dryrun": True}), flush=True)
+        sys.exit(int(os.environ.get("FHE_BENCH_DRYRUN_RC", "0")) if rank == world - 1 else 0)
+
+    import torch
+
     if world > 1:
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
@@ -230,7 +304,7 @@ def main():
         "dtype": "f64" if args.bits <= 50 else "u64",
         "data": "synthetic",
         "config": {
-            "workload": f"N=2^16 forward NTT, {args.limbs} x {args.bits}-bit prime(s), batch of {args.polys} residue polynomials per GPU "
+            "workload": f"BASELINE configs[1]: N=2^16 forward NTT, {args.limbs} x {args.bits}-bit prime(s) ({'ONE prime for the whole batch -- `value` and `roofline.frac` are this single-prime batch; the RNS-shaped batch of 16 distinct primes x 64 polynomials is `roofline.frac_L16`' if args.limbs == 1 else 'distinct primes per polynomial'}), batch of {args.polys} residue polynomials per GPU "
                         f"({batch_mib} MiB, {'exceeds' if streaming else 'fits'} the 256 MiB Infinity Cache), in place, resident on the device "
                         f"before the timed region",
             "log_n": LOGN, "limbs": args.limbs, "polys_per_gpu": args.polys, "prime_bits": args.bits,
@@ -369,6 +443,8 @@ def main():
         also["inverse_same_batch"] = rate(args.limbs, args.polys, args.bits, inverse=True, steps=100)
         also["L16_distinct_primes_x16_polys (configs[2] shape, 128 MiB)"] = rate(16, 16, args.bits)
         also["L16_distinct_primes_x64_polys (512 MiB, HBM streaming)"] = rate(16, 64, args.bits, steps=100)
+        # the RNS-shaped batch of the same size (BASELINE's metric says "L RNS limbs"): sixteen distinct primes, sixteen twiddle tables
+        result["roofline"]["frac_L16"] = also["L16_distinct_primes_x64_polys (512 MiB, HBM streaming)"]["frac_of_hbm_roofline"]
         also["61bit_prime_integer_path_same_batch"] = rate(1, args.polys, 61, steps=100)
 
         def pointwise_rates():
@@ -468,7 +544,9 @@ def main():
                 ntt_count = L + dnum * (L + K) - L + 2 * K + 2 * L + (2 + 2 * (L - 1) if kind == "hmult" else 0)
                 out[name] = {"us_per_call_device": dev * 1e3, "us_per_call_wall": wall_c * 1e6, "limb_ntts_per_call": ntt_count,
                              "limb_ntt_per_s_inside": ntt_count / (dev * 1e-3),
-                             "algorithmic_bytes": alg, "frac_of_hbm_roofline (inputs + key + outputs once)": alg / (dev * 1e-3) / 1e9 / HBM_PEAK_GBS}
+                             "algorithmic_bytes": alg, "frac_of_hbm_roofline (inputs + key + outputs once)": alg / (dev * 1e-3) / 1e9 / HBM_PEAK_GBS,
+                             "traffic_floor_us": traffic_floor_us(kind, logn, L, K, dnum),
+                             "frac_of_traffic_floor": traffic_floor_us(kind, logn, L, K, dnum) / (dev * 1e3)}
                 del ks, evk
             return out
         also.update(composite_rates())
@@ -544,11 +622,19 @@ def main():
             qk = F.create_moduli(n, [args.bits] * (L + K))
             tk = eng.tables(logn, qk)
             lay = ks_layout(L, K, world, rank)
-            mo = lay["cn"] + lay["sn"]
+            # every rank draws the SAME full operands (one seed) and keeps its own rows: rank 0 can then run the single-device
+            # composite on the full operands and compare it with the gathered result of the sharded run
             gg = torch.Generator(device="cuda")
-            gg.manual_seed(7 + rank)
+            gg.manual_seed(7)
             mk = lambda *shape: torch.randint(0, qk[0], shape, generator=gg, device="cuda", dtype=torch.int64)
-            c0, c1, b0, b1, gk = mk(lay["cn"], n), mk(lay["cn"], n), mk(lay["cn"], n), mk(lay["cn"], n), mk(dnum, 2, mo, n)
+            full = [mk(L, n) for _ in range(4)]
+            gk_full = mk(dnum, 2, L + K, n)
+            ct_rows = slice(lay["clo"], lay["clo"] + lay["cn"])
+            key_rows = list(range(lay["clo"], lay["clo"] + lay["cn"])) + list(range(lay["slo"], lay["slo"] + lay["sn"]))
+            c0, c1, b0, b1 = (x[ct_rows].contiguous() for x in full)
+            gk = gk_full[:, :, key_rows, :].contiguous()
+            if not (world > 1 and rank == 0):
+                del full, gk_full
             # every rank finishes its own set-up before the first collective: a rank that failed here must not leave the others
             # waiting inside an all-gather
             err = None
@@ -567,7 +653,39 @@ def main():
                 call = lambda tm=None: sharded_rotate(plan, c0, c1, 3, gk, timings=tm)
             else:
                 call = lambda tm=None: sharded_hmult(plan, c0, c1, b0, b1, gk, rescale=True, timings=tm)
+            equal = None
             with torch.cuda.stream(stream):
+                if world > 1:
+                    # untimed self-check of the first real multi-rank run: gather every rank's rows of the result on all ranks
+                    # (padded slabs, one in-place all-gather per part) and compare on rank 0 with fhe_rotate / fhe_hmult on one device
+                    from fhe_reliability_gpu_amd.dist import all_gather_slots
+                    outs = call()
+                    rows_max = lay["cmax"]
+                    got = []
+                    for part in outs:
+                        buf = torch.zeros((world * rows_max, n), dtype=torch.int64, device="cuda")
+                        buf[rank * rows_max:rank * rows_max + part.shape[0]] = part
+                        all_gather_slots(buf, rows_max)
+                        got.append(buf)
+                    torch.cuda.synchronize()
+                    if rank == 0:
+                        ks1 = F.KeySwitch(eng, tk, L, K, dnum)
+                        lo = L - 1 if kind == "hmult" else L
+                        w0, w1 = torch.empty((lo, n), dtype=torch.int64, device="cuda"), torch.empty((lo, n), dtype=torch.int64, device="cuda")
+                        if kind == "rotate":
+                            check(lib.fhe_rotate(eng._h, ks1._h, P(w0), P(w1), P(full[0]), P(full[1]), 3, P(gk_full), sptr))
+                        else:
+                            check(lib.fhe_hmult(eng._h, ks1._h, P(w0), P(w1), P(full[0]), P(full[1]), P(full[2]), P(full[3]), P(gk_full), 1, sptr))
+                        torch.cuda.synchronize()
+                        equal = True
+                        for r in range(world):
+                            lr = ks_layout(L, K, world, r)
+                            rows = [l for l in range(lr["clo"], lr["clo"] + lr["cn"]) if l < lo]
+                            for want, have in ((w0, got[0]), (w1, got[1])):
+                                if rows and not torch.equal(have[r * rows_max:r * rows_max + len(rows)], want[rows[0]:rows[0] + len(rows)]):
+                                    equal = False
+                        del ks1, w0, w1, full, gk_full
+                    del got
                 for _ in range(30):      # (a fixed count: every rank must issue the same collectives; enough to bring the clocks back up)
                     call()
                 barrier()
@@ -605,6 +723,9 @@ def main():
             if kind == "hmult":
                 out["us_broadcast (last limbs of both parts)"] = jb * 1e3
                 out["bytes_broadcast"] = 2 * n * 8
+            if world > 1:
+                out["sharded_equals_single"] = equal       # rank 0: gathered rows == fhe_rotate / fhe_hmult on one device, word for word
+            out["traffic_floor_us"] = traffic_floor_us(kind, logn, L, K, dnum)
             del plan
             return {name: out}
         # A collective that never completes (a rank lost, a fabric fault) must not cost the headline: past the limit every rank
@@ -619,7 +740,7 @@ def main():
                 also.setdefault("strong_scaling", {"error": "timed out: a sharded leg did not finish within the limit; the headline above is unaffected"})
                 result["also"] = also
                 print(json.dumps(result), flush=True)
-            os._exit(0)
+            os._exit(4)      # the line is out; the status says that a leg hung (a collective that never completed must not read as success)
         if world > 1:
             threading.Thread(target=watchdog, daemon=True).start()
         for kind in ("rotate", "hmult"):

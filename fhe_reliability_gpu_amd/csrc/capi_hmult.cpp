@@ -43,10 +43,12 @@ static int rescale_begin(fhe_ctx *ctx, fhe_keyswitch *p, const uint64_t *d_in, s
     const fhe_ntt_tables *t = p->t;
     const size_t N = (size_t)1 << p->log_n, cn = p->sh.cn, R = (size_t)p->L - 1, lr = R - p->sh.clo;   // lr: the last limb's row in this rank's slab
     int rc;
-    HIP_TRY(hipMemcpy2DAsync(p->rs_bc, N * 8, d_in + lr * N, cn * N * 8, N * 8, n_parts, hipMemcpyDeviceToDevice, st));
     {
+        // out of place: the parts' last limbs (cn rows apart in the caller's buffer) straight into rs_bc ([n_parts][N]), no copy
         TraceScope tr_ntt(ctx, st, "NTT");
         PassArgs a{p->rs_bc, t->d_lp.as<LimbParams>(), (u32)R, 1u, (u32)n_parts, 1u};
+        a.src = d_in + lr * N;
+        a.src_stride = (u32)cn;
         hipError_t e = launch_ntt(st, a, p->log_n, true, t->path[R], 1);
         if (e != hipSuccess) return hip_fail(e, "launch_ntt");
     }
@@ -106,6 +108,16 @@ static int rescale_check(fhe_ctx *ctx, fhe_keyswitch *p, const uint64_t *d_in, s
     return FHE_OK;
 }
 
+// Input parts are cn rows apart, output parts rs_n rows: in place the strides differ and later parts would be read after they were
+// overwritten.  Any overlap of an output part with the input is refused.
+static int rescale_overlap(const fhe_keyswitch *p, uint64_t *const *outs, const uint64_t *d_in, size_t n_parts)
+{
+    const size_t N = (size_t)1 << p->log_n, in_words = n_parts * (size_t)p->sh.cn * N, out_words = (size_t)p->rs_n * N;
+    for (size_t i = 0; i < n_parts; i++)
+        if (outs[i] && outs[i] < d_in + in_words && d_in < outs[i] + out_words) return fail(FHE_ERR_INVALID, "rescale is out of place");
+    return FHE_OK;
+}
+
 static int rescale_core(fhe_ctx *ctx, fhe_keyswitch *p, uint64_t *const *outs, const uint64_t *d_in, size_t n_parts, void *stream)
 {
     int rc = rescale_check(ctx, p, d_in, n_parts);
@@ -113,6 +125,7 @@ static int rescale_core(fhe_ctx *ctx, fhe_keyswitch *p, uint64_t *const *outs, c
     if (p->sharded) return fail(FHE_ERR_INVALID, "a sharded plan rescales through fhe_rescale_shard_begin / _finish with the broadcast between them");
     for (size_t i = 0; i < n_parts; i++)
         if (!outs[i]) return fail(FHE_ERR_INVALID, "null argument");
+    if (int rc2 = rescale_overlap(p, outs, d_in, n_parts)) return rc2;
     HIP_TRY(hipSetDevice(ctx->device));
     hipStream_t st = pick(ctx, stream);
     TraceScope tr(ctx, st, "RESCALE", true);
@@ -146,6 +159,8 @@ int fhe_rescale_shard_finish(fhe_ctx *ctx, fhe_keyswitch *p, uint64_t *d_out_loc
     HIP_TRY(hipSetDevice(ctx->device));
     const size_t step = (size_t)p->rs_n << p->log_n;
     uint64_t *outs[3] = {d_out_local, d_out_local + step, d_out_local + 2 * step};
+    if (p->rs_n)
+        if (int rc2 = rescale_overlap(p, outs, d_in_local, n_parts)) return rc2;
     return rescale_finish(ctx, p, outs, d_in_local, n_parts, pick(ctx, stream));
 }
 
@@ -163,6 +178,9 @@ int fhe_hmult(fhe_ctx *ctx, fhe_keyswitch *p, uint64_t *d_out0, uint64_t *d_out1
     if (!ctx || !p || !d_out0 || !d_out1 || !d_relin_key) return fail(FHE_ERR_INVALID, "null argument");
     if (rescale && p->L < 2) return fail(FHE_ERR_INVALID, "no prime left to drop");
     if (p->sharded) return fail(FHE_ERR_UNSUPPORTED, "fhe_hmult runs on one device; a sharded job runs fhe_tensor_product, the fhe_keyswitch_shard_* phases and fhe_rescale_shard_* on its rows");
+    // (the operands are read by the first launch only, the outputs written by the last: an output may reuse an operand's buffer; the
+    // two outputs must be distinct)
+    if (d_out0 == d_out1) return fail(FHE_ERR_INVALID, "the two output parts must be distinct buffers");
     const size_t N = (size_t)1 << p->log_n, L = p->L;
     u64 *d0 = p->hm.as<u64>(), *d1 = d0 + L * N, *d2 = d1 + L * N, *pre = p->hm_pre.as<u64>();
     int rc;

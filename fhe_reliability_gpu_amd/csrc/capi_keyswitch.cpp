@@ -215,20 +215,26 @@ static int ks_begin(fhe_ctx *ctx, fhe_keyswitch *p, const uint64_t *d_c, hipStre
 
 // base extension of each digit to every other owned prime (MODREDUCTION, 16384_4:471-452), their transforms, and the inner
 // product with the key (MULTEVK)
-static int ks_extend_mac(fhe_ctx *ctx, fhe_keyswitch *p, const uint64_t *d_c, const uint64_t *d_evk, hipStream_t st)
+// with the fused inner product only the FIRST launch of the extended limbs' forward transform runs on its own (the column
+// pass; nothing at all for single-pass sizes): the row pass happens inside the MULTEVK launch, tile by tile
+// (by shape: the fused launch has m_own x tiles workgroups, each looping over the digits -- it pays once that fills the chip)
+static bool ks_use_fused(const fhe_ctx *ctx, const fhe_keyswitch *p)
+{
+    const size_t MO = p->m_own;
+    const bool want = ctx->ks_fused < 0 ? (MO << (p->log_n > 12 ? p->log_n - 12 : 0)) >= 640 : ctx->ks_fused != 0;
+    return want && ks_rowmac_supported(p->log_n) && ctx->fault_idx < 0;
+}
+
+// the digits' extensions and the part of their forward transform that does not ride on the inner product (everything a hoisted
+// rotation shares between its Galois elements)
+static int ks_extend(fhe_ctx *ctx, fhe_keyswitch *p, hipStream_t st, bool fused)
 {
     const fhe_ntt_tables *t = p->t;
-    const KsShard &sh = p->sh;
     const size_t N = (size_t)1 << p->log_n, MO = p->m_own;
     const LimbParams *lp = t->d_lp.as<LimbParams>();
-    u64 *ext = p->ext.as<u64>(), *acc = p->acc.as<u64>();
+    u64 *ext = p->ext.as<u64>();
     hipError_t e;
     if (!MO) return FHE_OK;
-    // with the fused inner product only the FIRST launch of the extended limbs' forward transform runs on its own (the column
-    // pass; nothing at all for single-pass sizes): the row pass happens inside the MULTEVK launch, tile by tile
-    // (by shape: the fused launch has m_own x tiles workgroups, each looping over the digits -- it pays once that fills the chip)
-    const bool want = ctx->ks_fused < 0 ? (MO << (p->log_n > 12 ? p->log_n - 12 : 0)) >= 640 : ctx->ks_fused != 0;
-    const bool fused = want && ks_rowmac_supported(p->log_n) && ctx->fault_idx < 0;
     {
         // (one trace line for the phase; the nested NTT line precedes it, as the reference's tools expect of nested costs)
         TraceScope tr_mr(ctx, st, "MODREDUCTION");
@@ -252,12 +258,31 @@ static int ks_extend_mac(fhe_ctx *ctx, fhe_keyswitch *p, const uint64_t *d_c, co
             if ((e = launch_ntt(st, a, p->log_n, false, path, 1, fused ? 0 : -1)) != hipSuccess) return hip_fail(e, "launch_ntt");
         }
     }
-    // multiply-accumulate with the evaluation key (MULTEVK): all digits, both halves, one launch
+    return FHE_OK;
+}
+
+// multiply-accumulate with the evaluation key (MULTEVK): all digits, both halves, one launch
+static int ks_mac(fhe_ctx *ctx, fhe_keyswitch *p, const uint64_t *d_c, const uint64_t *d_evk, hipStream_t st, bool fused)
+{
+    const fhe_ntt_tables *t = p->t;
+    const KsShard &sh = p->sh;
+    const size_t MO = p->m_own;
+    const LimbParams *lp = t->d_lp.as<LimbParams>();
+    u64 *ext = p->ext.as<u64>(), *acc = p->acc.as<u64>();
+    hipError_t e;
+    if (!MO) return FHE_OK;
     TraceScope tr_mk(ctx, st, "MULTEVK");
     const KsMacArgs ka{acc, ext, d_c, d_evk, lp, (u32)p->L, (u32)MO, (u32)p->dnum, (u32)p->alpha, p->log_n, (u32)sh.cn, (u32)sh.clo, (u32)(sh.slo - sh.cn)};
     e = fused ? launch_ks_rowmac(st, ka, p->own_path[0], p->own_path[1]) : launch_ks_mac(st, ka);
     if (e != hipSuccess) return hip_fail(e, "launch_ks_mac");
     return FHE_OK;
+}
+
+static int ks_extend_mac(fhe_ctx *ctx, fhe_keyswitch *p, const uint64_t *d_c, const uint64_t *d_evk, hipStream_t st)
+{
+    const bool fused = ks_use_fused(ctx, p);
+    int rc = ks_extend(ctx, p, st, fused);
+    return rc ? rc : ks_mac(ctx, p, d_c, d_evk, st, fused);
 }
 
 // opening of the mod-down (MODSWITCH, 16384_4:454-463): the owned special limbs of both halves to coefficient form -- in
@@ -272,15 +297,21 @@ static int ks_special_intt(fhe_ctx *ctx, fhe_keyswitch *p, hipStream_t st)
     u64 *acc = p->acc.as<u64>(), *sp = acc + (size_t)sh.cn * N;
     u32 stride = (u32)MO;
     int rc;
+    // sharded: out of place, from acc straight into this rank's slot of gather buffer 2 (round 2 copied the rows there first)
+    const u64 *from = nullptr;
     if (p->sharded) {
+        from = sp;
         sp = p->g2 + (size_t)sh.rank * 2 * sh.smax * N;
         stride = (u32)sh.smax;
-        HIP_TRY(hipMemcpy2DAsync(sp, (size_t)sh.smax * N * 8, acc + (size_t)sh.cn * N, MO * N * 8, (size_t)sh.sn * N * 8, 2, hipMemcpyDeviceToDevice, st));
     }
     {
         TraceScope tr_ntt(ctx, st, "NTT");
         rc = for_each_run(t, sh.sn, sh.slo, [&](size_t off, size_t len, int path) -> int {
             PassArgs a{sp + off * N, lp, (u32)(sh.slo + off), (u32)len, (u32)(2 * len), stride, nullptr};
+            if (from) {
+                a.src = from + off * N;
+                a.src_stride = (u32)MO;
+            }
             hipError_t e2 = launch_ntt(st, a, p->log_n, true, path, 1);
             return e2 == hipSuccess ? FHE_OK : hip_fail(e2, "launch_ntt");
         });
@@ -304,8 +335,10 @@ static bool ks_fast_path(const fhe_ctx *ctx, const fhe_keyswitch *p)
 
 // rest of the mod-down, to the owned ciphertext limbs: conversion of the (gathered) special limbs to Q, NTT, subtract, times P^-1
 // (galois != 0: the addends are sigma_k(d_add*), read through the Galois map by the fused tail -- ks_fast_path() shapes only)
+// sp_hoist != nullptr (a hoisted rotation): the special limbs in coefficient form sit there ([2][K][N]) and the sums in acc are still in
+// the un-rotated frame -- the tail reads them through the Galois map as well
 static int ks_finish(fhe_ctx *ctx, fhe_keyswitch *p, uint64_t *d_out0, uint64_t *d_out1, const uint64_t *d_add0, const uint64_t *d_add1,
-                     hipStream_t st, u32 galois = 0)
+                     hipStream_t st, u32 galois = 0, const u64 *sp_hoist = nullptr)
 {
     const fhe_ntt_tables *t = p->t;
     const KsShard &sh = p->sh;
@@ -319,8 +352,9 @@ static int ks_finish(fhe_ctx *ctx, fhe_keyswitch *p, uint64_t *d_out0, uint64_t 
     if (plain && galois) return fail(FHE_ERR_INVALID, "the Galois map on the addends belongs to the fused tail");
     // one special prime at a two-launch size: the conversion x mod q_j rides on the converted limbs' column pass
     const bool trivial = p->K == 1 && p->log_n >= 13 && !plain;
+    if (sp_hoist && plain) return fail(FHE_ERR_UNSUPPORTED, "hoisted rotations need the fused mod-down tail");
     if (!trivial) {
-        e = launch_baseconv_exact_jobs(st, p->down_jobs.as<BcJob>(), 2, p->down->dev.m, p->down->dev.k, p->down->dev.f64 != 0, N, p->down->dev.m <= 16 ? 1u << (p->down->dev.m - 1) : 0u);
+        e = launch_baseconv_exact_jobs(st, (sp_hoist ? p->hdown_jobs : p->down_jobs).as<BcJob>(), 2, p->down->dev.m, p->down->dev.k, p->down->dev.f64 != 0, N, p->down->dev.m <= 16 ? 1u << (p->down->dev.m - 1) : 0u);
         if (e != hipSuccess) return hip_fail(e, "launch_baseconv_exact_jobs");
         if (p->plain_modulus && (rc = fhe_scalar_affine(ctx, conv, conv, p->t_mod_Q.data() + sh.clo, nullptr, t, 2, sh.cn, sh.clo, st))) return rc;
     }
@@ -338,9 +372,10 @@ static int ks_finish(fhe_ctx *ctx, fhe_keyswitch *p, uint64_t *d_out0, uint64_t 
         RowEpiArgs ep{{d_out0 + off * N, d_out1 + off * N, nullptr}, {d_add0 ? d_add0 + off * N : nullptr, d_add1 ? d_add1 + off * N : nullptr, nullptr},
                       acc + off * N, (u64)(MO * N), p->pinv.as<u64>() + off};
         ep.galois = galois;
+        ep.galois_a = sp_hoist ? 1u : 0u;
         if (trivial) {
-            a.src = (p->sharded ? p->g2 : acc) + (size_t)p->down_src_row * N;
-            a.src_bcast = (u64)p->down_src_stride * N;
+            a.src = sp_hoist ? sp_hoist : (p->sharded ? p->g2 : acc) + (size_t)p->down_src_row * N;
+            a.src_bcast = sp_hoist ? (u64)p->K * N : (u64)p->down_src_stride * N;
             if (p->plain_modulus) ep.pre = p->d_t_mod_Q.as<u64>() + sh.clo + off;     // BGV: delta = t * [acc t^-1]_P
         }
         hipError_t e2 = launch_ntt_subscale(st, a, ep, p->log_n, path);
@@ -499,7 +534,7 @@ int fhe_rotate(fhe_ctx *ctx, fhe_keyswitch *p, uint64_t *d_out0, uint64_t *d_out
                uint32_t galois_elt, const uint64_t *d_galois_key, void *stream)
 {
     if (!ctx || !p || !d_out0 || !d_out1 || !d_c0 || !d_c1 || !d_galois_key) return fail(FHE_ERR_INVALID, "null argument");
-    if (d_out0 == d_c0 || d_out1 == d_c1) return fail(FHE_ERR_INVALID, "rotate is out of place");
+    if (d_out0 == d_c0 || d_out1 == d_c1 || d_out0 == d_c1 || d_out1 == d_c0 || d_out0 == d_out1) return fail(FHE_ERR_INVALID, "rotate is out of place");
     if (!(galois_elt & 1)) return fail(FHE_ERR_INVALID, "Galois elements are odd");
     if (p->sharded)
         return fail(FHE_ERR_INVALID, "a sharded plan runs through fhe_rotate_shard_begin / _inner / _finish with the all-gathers between them");
@@ -518,6 +553,102 @@ int fhe_rotate(fhe_ctx *ctx, fhe_keyswitch *p, uint64_t *d_out0, uint64_t *d_out
     TraceScope tr_ms(ctx, st, "MODSWITCH");
     if ((rc = ks_special_intt(ctx, p, st))) return rc;
     return rotate_finish(ctx, p, d_out0, d_out1, d_c0, galois_elt, st);
+}
+
+// ---------------------------------------------------------------- hoisted rotations
+// Rotations of ONE ciphertext by several Galois elements (the baby steps of a BSGS matrix-vector product,
+// profile_framewk/src/matmul_ckks.cpp:45-113; the rotate-and-sum of reliability_test/dotprod_test.cu:143-148): the decomposition of c1
+// -- INTT, digit extension, the extended limbs' forward transform up to the launch the inner product rides on -- does not depend on
+// the Galois element and is done once.  sigma is a ring automorphism, so
+//     sum_d sigma(ext_d) * key_d  =  sigma( sum_d ext_d * sigma^-1(key_d) ):
+// with the key stored in the un-rotated frame (fhe_galois_key_prepare: sigma^-1 of every key row, once per key) the inner product
+// runs on the shared digits exactly as a plain key switch's, and sigma is taken on loads the mod-down makes anyway: the special limbs'
+// INTT reads its sums through the Galois map, the fused tail reads the ciphertext limbs' sums and c0 through it.
+// The result is the rotation with ext_d = sigma(extension of c1's digit) where fhe_rotate uses the extension of sigma(c1)'s digit: the
+// two differ by multiples of the digit modulus where sigma flips a sign (the exact extension lifts to [0, P_d), which negation does not
+// preserve), so the words differ while both are valid key switches of sigma(c1) (tests/: oracle rotate_hoisted_ref word for word, and
+// the decryption of both).
+static int hoist_buffers(fhe_ctx *ctx, fhe_keyswitch *p)
+{
+    if (p->hsp.p) return FHE_OK;
+    const size_t N = (size_t)1 << p->log_n, K = p->K;
+    HIP_TRY(hipSetDevice(ctx->device));
+    HIP_TRY(p->hsp.alloc(2 * K * N * 8));
+    std::vector<u32> rows(2 * K);
+    for (size_t i = 0; i < 2 * K; i++) rows[i] = (u32)i;
+    HIP_TRY(p->hdown_rows.upload(rows));
+    std::vector<BcJob> down;
+    for (int h = 0; h < 2; h++)
+        down.push_back(BcJob{p->down->dev, p->hsp.as<u64>(), p->conv.as<u64>() + (size_t)h * p->sh.cn * N, 0xFFFFFFFFu, 0u, p->hdown_rows.as<u32>() + (size_t)h * K});
+    HIP_TRY(p->hdown_jobs.upload(down));
+    return FHE_OK;
+}
+
+extern "C" int fhe_galois_key_prepare(fhe_ctx *ctx, fhe_keyswitch *p, uint64_t *d_key_out, const uint64_t *d_key_in, uint32_t galois_elt, void *stream)
+{
+    if (!ctx || !p || !d_key_out || !d_key_in || d_key_out == d_key_in || !(galois_elt & 1)) return fail(FHE_ERR_INVALID, "bad arguments");
+    // sigma_k^-1 = sigma_{k^-1 mod 2N}
+    const u64 two_n = (u64)2 << p->log_n;
+    const u64 kinv = host::inv_mod(galois_elt % two_n, two_n);
+    if (!kinv) return fail(FHE_ERR_INVALID, "Galois elements are odd");
+    HIP_TRY(hipSetDevice(ctx->device));
+    hipError_t e = launch_automorphism_ntt(pick(ctx, stream), d_key_out, d_key_in, (u32)((size_t)p->dnum * 2 * p->m_own), p->log_n, (u32)kinv);
+    if (e != hipSuccess) return hip_fail(e, "launch_automorphism_ntt");
+    return FHE_OK;
+}
+
+extern "C" int fhe_rotate_hoisted(fhe_ctx *ctx, fhe_keyswitch *p, uint64_t *const *d_out0, uint64_t *const *d_out1, const uint64_t *d_c0,
+                                  const uint64_t *d_c1, const uint32_t *galois_elts, const uint64_t *const *d_prepared_keys, size_t n_rot, void *stream)
+{
+    if (!ctx || !p || !d_c0 || !d_c1 || (n_rot && (!d_out0 || !d_out1 || !galois_elts || !d_prepared_keys))) return fail(FHE_ERR_INVALID, "null argument");
+    if (p->sharded) return fail(FHE_ERR_UNSUPPORTED, "hoisted rotations run on one device");
+    if (p->log_n < 5 || !ks_fast_path(ctx, p)) return fail(FHE_ERR_UNSUPPORTED, "hoisted rotations need N >= 2^5 and the default transform path");
+    for (size_t r = 0; r < n_rot; r++) {
+        if (!d_out0[r] || !d_out1[r] || !d_prepared_keys[r]) return fail(FHE_ERR_INVALID, "null argument");
+        if (!(galois_elts[r] & 1)) return fail(FHE_ERR_INVALID, "Galois elements are odd");
+        if (d_out0[r] == d_c0 || d_out1[r] == d_c0 || d_out0[r] == d_c1 || d_out1[r] == d_c1 || d_out0[r] == d_out1[r])
+            return fail(FHE_ERR_INVALID, "rotate is out of place");
+    }
+    if (!n_rot) return FHE_OK;
+    int rc = hoist_buffers(ctx, p);
+    if (rc) return rc;
+    HIP_TRY(hipSetDevice(ctx->device));
+    hipStream_t st = pick(ctx, stream);
+    const fhe_ntt_tables *t = p->t;
+    const size_t N = (size_t)1 << p->log_n, MO = p->m_own, L = p->L, K = p->K;
+    const LimbParams *lp = t->d_lp.as<LimbParams>();
+    const bool fused = ks_use_fused(ctx, p);
+    // shared: decomposition of c1 (no automorphism yet)
+    {
+        TraceScope tr(ctx, st, "HOIST");
+        if ((rc = ks_begin(ctx, p, d_c1, st))) return rc;
+        if ((rc = ks_extend(ctx, p, st, fused))) return rc;
+    }
+    u64 *acc = p->acc.as<u64>(), *hsp = p->hsp.as<u64>();
+    for (size_t r = 0; r < n_rot; r++) {
+        TraceScope tr(ctx, st, "ROTATE", true);
+        const u32 g = galois_elts[r];
+        if ((rc = ks_mac(ctx, p, d_c1, d_prepared_keys[r], st, fused))) return rc;
+        TraceScope tr_ms(ctx, st, "MODSWITCH");
+        // INTT of sigma(special limbs of the sums), out of place: acc ([2][M][N], special limbs from row L) -> hsp ([2][K][N])
+        {
+            TraceScope tr_ntt(ctx, st, "NTT");
+            rc = for_each_run(t, K, L, [&](size_t off, size_t len, int path) -> int {
+                PassArgs a{hsp + off * N, lp, (u32)(L + off), (u32)len, (u32)(2 * len), (u32)K, nullptr};
+                a.src = acc + (L + off) * N;
+                a.src_stride = (u32)MO;
+                a.galois = g;
+                hipError_t e2 = launch_ntt(st, a, p->log_n, true, path, 1);
+                return e2 == hipSuccess ? FHE_OK : hip_fail(e2, "launch_ntt");
+            });
+            if (rc) return rc;
+        }
+        if (p->plain_modulus)
+            for (int h = 0; h < 2; h++)
+                if ((rc = fhe_scalar_affine(ctx, hsp + (size_t)h * K * N, hsp + (size_t)h * K * N, p->t_inv_P.data(), nullptr, t, 1, K, L, st))) return rc;
+        if ((rc = ks_finish(ctx, p, d_out0[r], d_out1[r], d_c0, nullptr, st, g, hsp))) return rc;
+    }
+    return FHE_OK;
 }
 
 // The three phases of a rotation on a limb-sharded plan (the joins between them are the key switch's, fhe_keyswitch_shard_*): the
@@ -542,6 +673,8 @@ int fhe_rotate_shard_finish(fhe_ctx *ctx, fhe_keyswitch *p, uint64_t *d_out0_loc
                             uint32_t galois_elt, void *stream)
 {
     if (!ctx || !p || ((!d_out0_local || !d_out1_local || !d_c0_local) && p->sh.cn) || !(galois_elt & 1)) return fail(FHE_ERR_INVALID, "bad rotation arguments");
+    // the tail reads c0 through the Galois permutation while it writes out0: in place, later tiles would read words already overwritten
+    if (p->sh.cn && (d_out0_local == d_c0_local || d_out1_local == d_c0_local)) return fail(FHE_ERR_INVALID, "rotate is out of place");
     HIP_TRY(hipSetDevice(ctx->device));
     return rotate_finish(ctx, p, d_out0_local, d_out1_local, d_c0_local, galois_elt, pick(ctx, stream));
 }

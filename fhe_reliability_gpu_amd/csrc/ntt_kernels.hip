@@ -819,6 +819,7 @@ struct SubScaleTap {
     const u64 *add_limb;        // galois != 0: the addend is sigma_k(add) -- read through the Galois map from the limb's first word
     u32 pos0, galois;           // (index of the tile's first word inside its limb; a rotation's sigma(c0), RowEpiArgs::galois)
     int logn;
+    const u64 *acc_limb;        // != nullptr: `acc` too is read through the Galois map, from this limb base (RowEpiArgs::galois_a)
     template <class E, class C> FHE_D void in(u32, E, const C &) {}
     // integer form (ArithU64 limbs; any 64-bit words)
     FHE_D u64 one_int(u64 a, u64 x, u64 t, bool has_add) const
@@ -850,7 +851,9 @@ struct SubScaleTap {
     }
     FHE_D void store(u32 idx, u64 x0, u64 x1)
     {
-        const ulonglong2 a = *reinterpret_cast<const ulonglong2 *>(acc + idx);
+        ulonglong2 a;
+        if (acc_limb) a = ulonglong2{acc_limb[galois_slot(pos0 + idx, logn, galois)], acc_limb[galois_slot(pos0 + idx + 1, logn, galois)]};
+        else a = *reinterpret_cast<const ulonglong2 *>(acc + idx);
         ulonglong2 t = ulonglong2{0, 0};
         if (add) {
             if (galois) t = ulonglong2{add_limb[galois_slot(pos0 + idx, logn, galois)], add_limb[galois_slot(pos0 + idx + 1, logn, galois)]};
@@ -886,7 +889,8 @@ __global__ __launch_bounds__(NTT_THREADS) void k_ntt_row_subscale(PassArgs a, Ro
     const int tid = threadIdx.x;
     const size_t eoff = ((size_t)l << LOGN) + (size_t)row0 * PASS::NPTS;      // element offset inside part h
     SubScaleTap<A> tap{ep.a + (size_t)h * ep.a_stride + eoff, ep.add[h] ? ep.add[h] + eoff : nullptr, ep.out[h] + eoff, ep.scal[l], p.q, p.barrett_lo, p.barrett_hi,
-                       ep.pre ? ep.pre[l] : 0, p.n, p.ninv, ep.add[h] ? ep.add[h] + ((size_t)l << LOGN) : nullptr, row0 * (u32)PASS::NPTS, ep.galois, LOGN};
+                       ep.pre ? ep.pre[l] : 0, p.n, p.ninv, ep.add[h] ? ep.add[h] + ((size_t)l << LOGN) : nullptr, row0 * (u32)PASS::NPTS, ep.galois, LOGN,
+                       ep.galois && ep.galois_a ? ep.a + (size_t)h * ep.a_stride + ((size_t)l << LOGN) : nullptr};
     const u64 *from = pass_source<PASS, LOGN, false>(a, base, row0);
     PASS::template phase<0>(tid, base, lds, tw, row0, ctx, inv_n, &tap, from);
     if constexpr (PASS::NPHASE > 1) {

@@ -29,6 +29,7 @@ struct RowEpiArgs {
     const u64 *scal;
     const u64 *pre = nullptr;   // optional per-limb factor applied to the transformed words first (t of the BGV forms)
     u32 galois = 0;             // != 0: the addends are sigma_k(add[h]), read through the NTT-domain Galois map (a rotation's sigma(c0))
+    u32 galois_a = 0;           // != 0 (with galois): `a` is read through the same map too -- a hoisted rotation's sums, formed in the un-rotated frame
 };
 bool ntt_subscale_supported(int logn);
 hipError_t launch_ntt_subscale(hipStream_t st, const PassArgs &a, const RowEpiArgs &ep, int logn, int path);

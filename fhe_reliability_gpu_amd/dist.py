@@ -334,12 +334,15 @@ def sharded_rotate(plan, c0_local, c1_local, galois_elt: int, gk_local, timings=
 
 
 def broadcast_rows(buf, src: int, group=None):
-    """In-place broadcast of ``buf`` from rank ``src`` (CUDA tensors under gloo are staged through host memory)."""
+    """In-place broadcast of ``buf`` from rank ``src`` OF ``group`` (CUDA tensors under gloo are staged through host memory).
+    torch.distributed.broadcast takes the source as a GLOBAL rank: a group rank is translated first."""
     import torch.distributed as dist
 
     world, _ = _group_info(group)
     if world == 1 and not (dist.is_available() and dist.is_initialized()):
         return
+    if group is not None:
+        src = dist.get_global_rank(group, src)
     if buf.is_cuda and dist.get_backend(group) == "gloo":
         host = buf.cpu()
         dist.broadcast(host, src=src, group=group)

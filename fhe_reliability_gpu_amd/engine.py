@@ -446,6 +446,29 @@ class KeySwitch:
         check(lib.fhe_rotate(self.eng._h, self._h, o0.ptr, o1.ptr, c0.ptr, c1.ptr, galois_elt, galois_key.ptr, stream))
         return o0, o1
 
+    def prepare_galois_key(self, galois_key: DeviceArray, galois_elt: int, stream=None) -> DeviceArray:
+        """The key in the un-rotated frame (sigma^-1 of every key row): what ``rotate_hoisted`` takes; once per key."""
+        out = self.eng.alloc(self.dnum * 2 * (self.L + self.K) * self.t.N)
+        out.shape = (self.dnum, 2, self.L + self.K, self.t.N)
+        check(lib.fhe_galois_key_prepare(self.eng._h, self._h, out.ptr, galois_key.ptr, galois_elt, stream))
+        return out
+
+    def rotate_hoisted(self, c0: DeviceArray, c1: DeviceArray, galois_elts, prepared_keys, stream=None):
+        """Rotations of ONE ciphertext by several Galois elements with the decomposition of c1 shared (the baby steps of
+        profile_framewk/src/matmul_ckks.cpp:45-113): a list of (out0, out1)."""
+        n = len(galois_elts)
+        outs = []
+        for _ in range(n):
+            o0, o1 = self.eng.alloc(self.L * self.t.N), self.eng.alloc(self.L * self.t.N)
+            o0.shape = o1.shape = (self.L, self.t.N)
+            outs.append((o0, o1))
+        a0 = (vp * n)(*[o[0].ptr for o in outs])
+        a1 = (vp * n)(*[o[1].ptr for o in outs])
+        ks = (vp * n)(*[k.ptr for k in prepared_keys])
+        ge = (C.c_uint32 * n)(*[int(g) for g in galois_elts])
+        check(lib.fhe_rotate_hoisted(self.eng._h, self._h, a0, a1, c0.ptr, c1.ptr, ge, ks, n, stream))
+        return outs
+
     def set_plain_modulus(self, t: int):
         """BGV form of the mod-down and of the rescale (0 = CKKS-style flooring)."""
         check(lib.fhe_keyswitch_set_plain_modulus(self._h, t))

@@ -151,6 +151,9 @@ int fhe_ntt_cyclic(fhe_ctx *ctx, uint64_t *d_data, uint64_t *d_scratch, int log_
 /* four_step_ntt(a, N) of reliability_test/four_step_ntt_prot.py:71-109 with N = n1*n2
  * (both powers of two, n1 != n2 allowed, N <= 2^20): column transforms, twiddle w^(k2 t1), row
  * transforms, transposed output; equals ntt_direct (:49-58).  g = generator (G=3, :17). */
+/* Range: n1 * n2 <= 2^20 and mod < 2^61 (FHE_ERR_INVALID / FHE_ERR_UNSUPPORTED beyond: the two-launch natural-order transform
+ * covers the sizes the engine's tile plans cover; round 1's transpose / twiddle composition, which reached 2^26, is gone).
+ * A plan's hand-off buffer is reused by every call on it: one plan, one stream at a time (see fhe_hmult). */
 int fhe_fourstep_create(fhe_ctx *ctx, uint64_t n1, uint64_t n2, uint64_t mod, uint64_t g, fhe_fourstep **out);
 int fhe_fourstep_destroy(fhe_fourstep *p);
 int fhe_fourstep_ntt(fhe_ctx *ctx, uint64_t *d_dst, const uint64_t *d_src, fhe_fourstep *p, void *stream);
@@ -261,8 +264,22 @@ int fhe_keyswitch_apply(fhe_ctx *ctx, fhe_keyswitch *p, uint64_t *d_out0, uint64
  * (dotprod_test.cu:146), frontend "ROTATE" of the reference's traces (16384_4:466-539): apply
  * x -> x^galois_elt to both parts, key-switch the second part with the Galois key, add.
  * out0 + out1*s ~ sigma(c0 + c1*s). */
+/* OUT OF PLACE: the parts are read through the Galois permutation while the outputs are written -- neither output may be one of the
+ * input parts (FHE_ERR_INVALID); the same holds for fhe_rotate_shard_finish's d_c0_local. */
 int fhe_rotate(fhe_ctx *ctx, fhe_keyswitch *p, uint64_t *d_out0, uint64_t *d_out1, const uint64_t *d_c0, const uint64_t *d_c1,
                uint32_t galois_elt, const uint64_t *d_galois_key, void *stream);
+/* Hoisted rotations: n_rot rotations of ONE ciphertext (the baby steps of a BSGS matrix-vector product,
+ * profile_framewk/src/matmul_ckks.cpp:45-113; rotate-and-sum, reliability_test/dotprod_test.cu:143-148).  The decomposition of c1 --
+ * INTT, digit extension, the extended limbs' forward transform -- is shared; per Galois element only the inner product with the key
+ * and the mod-down run (sigma is taken on the mod-down's loads).  Keys are given in the UN-ROTATED frame:
+ * d_prepared_keys[r] = fhe_galois_key_prepare(key of galois_elts[r]) = sigma^-1 of every key row, computed once per key (layout
+ * unchanged, [dnum][2][L+K][N]).  d_out0 / d_out1 / d_prepared_keys are HOST arrays of n_rot device pointers.
+ * Each result is a rotation of (c0, c1) by its element -- out0 + out1 s ~ sigma(c0 + c1 s) -- with ext_d = sigma(extension of c1's
+ * digit); fhe_rotate extends sigma(c1)'s digit instead, so the two differ word by word (by multiples of the digit moduli where sigma
+ * flips a sign) while decrypting to the same plaintext.  One device, N >= 2^5, out of place. */
+int fhe_galois_key_prepare(fhe_ctx *ctx, fhe_keyswitch *p, uint64_t *d_key_out, const uint64_t *d_key_in, uint32_t galois_elt, void *stream);
+int fhe_rotate_hoisted(fhe_ctx *ctx, fhe_keyswitch *p, uint64_t *const *d_out0, uint64_t *const *d_out1, const uint64_t *d_c0,
+                       const uint64_t *d_c1, const uint32_t *galois_elts, const uint64_t *const *d_prepared_keys, size_t n_rot, void *stream);
 /* The same rotation on a limb-sharded plan (fhe_keyswitch_create_sharded): the automorphism permutes slots inside a limb, so each
  * rank applies it to its own rows -- on the loads of the launches below, there is no permuted copy of c0 and no launch for it.
  * Phases and joins as for the sharded key switch:
@@ -289,6 +306,7 @@ int fhe_relinearize(fhe_ctx *ctx, fhe_keyswitch *p, uint64_t *d_out0, uint64_t *
  * c' = (c - [c]_{q_last}) / q_last on each of n_parts (1..3) parts; d_in = [n_parts][L][N], d_out = [n_parts][L-1][N],
  * NTT domain.  With a plain modulus set on the plan (BGV) the removed part is t [c t^-1]_{q_last}, so the plaintext is
  * kept up to the factor q_last^-1 mod t. */
+/* OUT OF PLACE: input parts are L rows apart, output parts L-1 -- d_out must not overlap d_in (FHE_ERR_INVALID). */
 int fhe_rescale(fhe_ctx *ctx, fhe_keyswitch *p, uint64_t *d_out, const uint64_t *d_in, size_t n_parts, void *stream);
 /* fhe_rescale with the limbs sharded (plans of fhe_keyswitch_create_sharded with a d_bcast buffer): d_in_local = [n_parts][cn][N], the
  * rows this rank owns.  _begin: the owner of limb L-1 (fhe_rescale_shard_info: owns_last) turns the last limb of every part to
@@ -299,6 +317,12 @@ int fhe_rescale_shard_begin(fhe_ctx *ctx, fhe_keyswitch *p, const uint64_t *d_in
 int fhe_rescale_shard_finish(fhe_ctx *ctx, fhe_keyswitch *p, uint64_t *d_out_local, const uint64_t *d_in_local, size_t n_parts, void *stream);
 /* The three steps above in one call (multiply -> relinearize -> mod_switch, dotprod_test.cu:113-115) on two two-part
  * ciphertexts of L limbs; rescale != 0: outputs have L-1 limbs, else L.  The plan owns the intermediates. */
+/* The operands are consumed by the first launch (tensor product into plan-owned buffers), so an output may reuse an operand's
+ * buffer; d_out0 and d_out1 must be distinct.
+ * ONE PLAN, ONE STREAM AT A TIME: a plan (fhe_keyswitch, fhe_fourstep, fhe_abft) owns scratch buffers -- extended digits, sums,
+ * converted limbs, the tensor product, rescale residues, the four-step hand-off, checksum partials -- that every call on it
+ * reuses.  Calls on the SAME plan must be ordered by one stream (or by the caller's events); different plans, and the plan-less
+ * transforms / products, may run on different streams concurrently. */
 int fhe_hmult(fhe_ctx *ctx, fhe_keyswitch *p, uint64_t *d_out0, uint64_t *d_out1, const uint64_t *d_a0, const uint64_t *d_a1,
               const uint64_t *d_b0, const uint64_t *d_b1, const uint64_t *d_relin_key, int rescale, void *stream);
 

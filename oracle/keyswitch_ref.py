@@ -29,9 +29,11 @@ def _tables(qs, logn):
     return np.stack([O.root_powers(q, logn) for q in qs])
 
 
-def keyswitch_ref(c, evk, qs, L, K, dnum, logn, add0=None, add1=None, rps=None, plain_modulus=0):
+def keyswitch_ref(c, evk, qs, L, K, dnum, logn, add0=None, add1=None, rps=None, plain_modulus=0, sigma_ext=0):
     """c: (L, N) NTT domain; evk: (dnum, 2, L+K, N) NTT domain; returns (out0, out1), each (L, N).
     add0 / add1: optional (L, N) terms added to the outputs (rotation: sigma(c0); relinearisation: d0, d1).
+    sigma_ext (a Galois element; hoisted rotations): the automorphism is applied to every digit's extension AFTER it was formed
+    from the un-rotated input, ext_d <- sigma(ext_d), instead of to the input (the decomposition is then shared by all elements).
     plain_modulus t (BGV form of the mod-down, the scheme of reliability_test/dotprod_test.cu:199-204): the removed part is
     t * [acc t^-1]_P instead of [acc]_P, so that it vanishes modulo t."""
     M, N = L + K, 1 << logn
@@ -48,6 +50,10 @@ def keyswitch_ref(c, evk, qs, L, K, dnum, logn, add0=None, add1=None, rps=None, 
         ext = np.zeros((M, N), dtype=np.uint64)
         ext[other] = O.nwt_forward_batch(conv, [qs[j] for j in other], rps[other])
         ext[lo:hi] = c[lo:hi]
+        if sigma_ext:
+            co = O.nwt_inverse_batch(ext, qs, rps)
+            co = np.stack([galois_coeff(co[j], sigma_ext, qs[j]) for j in range(M)])
+            ext = O.nwt_forward_batch(co, qs, rps)
         for h in range(2):                                                                     # MULTEVALK
             acc[h] = O.modmul_batch(ext, evk[d, h], qs, acc=acc[h])
     outs = []
@@ -89,6 +95,18 @@ def rotate_ref(c0, c1, k, gk, qs, L, K, dnum, logn):
         return O.nwt_forward_batch(co, qs[:L], rps[:L])
 
     return keyswitch_ref(sigma(c1), gk, qs, L, K, dnum, logn, add0=sigma(c0), rps=rps)
+
+
+def rotate_hoisted_ref(c0, c1, k, gk, qs, L, K, dnum, logn):
+    """One rotation out of a hoisted batch (fhe_rotate_hoisted): the digits of the UN-rotated c1 are extended once, sigma_k is applied to
+    the extended digits, then inner product with the (standard) Galois key, mod-down, plus sigma(c0).  Differs from rotate_ref word by
+    word -- the exact extension lifts a digit to [0, P_d), which sigma's sign flips do not preserve -- and decrypts to the same value."""
+    qs = [int(q) for q in qs]
+    rps = _tables(qs, logn)
+    co = O.nwt_inverse_batch(np.asarray(c0, dtype=np.uint64), qs[:L], rps[:L])
+    co = np.stack([galois_coeff(co[l], k, qs[l]) for l in range(L)])
+    sig0 = O.nwt_forward_batch(co, qs[:L], rps[:L])
+    return keyswitch_ref(c1, gk, qs, L, K, dnum, logn, add0=sig0, rps=rps, sigma_ext=k)
 
 
 def tensor_ref(a0, a1, b0, b1, qs):

@@ -103,7 +103,19 @@ def _nccl_worker(rank, world, port, out_dir):
         s0, s1 = sharded_hmult(plan, _to_cuda(c), _to_cuda(add), _to_cuda(add), _to_cuda(c), _to_cuda(evk))
         torch.cuda.synchronize()
         ok_hm = bool((_from_cuda(s0) == h0.download()).all() and (_from_cuda(s1) == h1.download()).all())
-        np.save(os.path.join(out_dir, f"nccl{rank}.npy"), np.array([ok_ks, ok_rot, ok_bc, ok_hm, gather_ms >= 0.0, dist.get_backend() == "nccl"]))
+        # the same composites issued from a USER stream (no side stream, no fences of stream_scope: phase kernels, the in-place
+        # ncclAllGather and the broadcast are ordered by the one stream) and on a plan bound to a NON-default group (the broadcast's
+        # source is a group rank there: dist.broadcast_rows translates it)
+        sub = dist.new_group([0])
+        plan_g = ShardedKeySwitch(eng, t, L, K, dnum, group=sub)
+        user = torch.cuda.Stream()
+        with torch.cuda.stream(user):
+            u0, u1 = sharded_rotate(plan, _to_cuda(add), _to_cuda(c), 5, _to_cuda(evk))
+            m0, m1 = sharded_hmult(plan_g, _to_cuda(c), _to_cuda(add), _to_cuda(add), _to_cuda(c), _to_cuda(evk))
+            user.synchronize()
+        ok_user = bool((_from_cuda(u0) == v0).all() and (_from_cuda(u1) == v1).all() and (_from_cuda(m0) == h0.download()).all()
+                       and (_from_cuda(m1) == h1.download()).all())
+        np.save(os.path.join(out_dir, f"nccl{rank}.npy"), np.array([ok_ks, ok_rot, ok_bc, ok_hm, gather_ms >= 0.0, dist.get_backend() == "nccl", ok_user]))
     finally:
         dist.destroy_process_group()
 
@@ -115,7 +127,7 @@ def test_rccl_join_executes_on_one_rank(tmp_path):
     import torch.multiprocessing as mp
     mp.spawn(_nccl_worker, args=(1, _free_port(), str(tmp_path)), nprocs=1, join=True)
     flags = np.load(tmp_path / "nccl0.npy")
-    assert flags.all(), f"(keyswitch, rotate, baseconv, hmult, timings, backend) = {flags.tolist()}"
+    assert flags.all(), f"(keyswitch, rotate, baseconv, hmult, timings, backend, user stream + subgroup) = {flags.tolist()}"
 
 
 def _gloo_gpu_hmult_worker(rank, world, port, logn, L, K, dnum, bits, out_dir):

@@ -1,0 +1,183 @@
+"""Hoisted rotations (profile_framewk/src/matmul_ckks.cpp:45-113, reliability_test/dotprod_test.cu:143-148):
+several Galois elements applied to ONE ciphertext with the decomposition of c1 shared.  Word for word against the oracle composite
+(oracle/keyswitch_ref.py rotate_hoisted_ref: sigma applied to the extended digits), at the decryption level against fhe_rotate (the
+two key switches differ word by word -- the exact extension lifts to [0, P_d), which sigma's sign flips do not preserve -- and
+decrypt to the same plaintext), the prepared key against sigma^-1 of the key, and the error statuses of the new entry points."""
+import ctypes as C
+import random
+
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def F():
+    import fhe_reliability_gpu_amd as f
+    return f
+
+
+@pytest.fixture(scope="module")
+def eng(F):
+    return F.default_engine()
+
+
+def _rand_case(F, logn, L, K, dnum, bits, seed):
+    N = 1 << logn
+    qs = F.create_moduli(N, [bits] * L + [61 if bits == 61 else 50] * K)
+    rng = np.random.default_rng(seed)
+    c0 = np.stack([rng.integers(0, q, N, dtype=np.uint64) for q in qs[:L]])
+    c1 = np.stack([rng.integers(0, q, N, dtype=np.uint64) for q in qs[:L]])
+    keys = [np.stack([np.stack([np.stack([rng.integers(0, q, N, dtype=np.uint64) for q in qs]) for _ in range(2)]) for _ in range(dnum)]) for _ in range(3)]
+    return qs, c0, c1, keys
+
+
+@pytest.mark.parametrize("logn,L,K,dnum,bits", [(5, 3, 1, 3, 50), (10, 4, 2, 2, 50), (12, 6, 2, 3, 61), (13, 4, 1, 4, 50), (13, 5, 2, 2, 50),
+                                                (14, 5, 2, 3, 61), (16, 3, 1, 3, 50)])
+def test_hoisted_rotations_match_oracle_composite(F, eng, logn, L, K, dnum, bits):
+    from oracle.keyswitch_ref import rotate_hoisted_ref, rotate_ref
+    N = 1 << logn
+    qs, c0, c1, keys = _rand_case(F, logn, L, K, dnum, bits, logn * 17 + L)
+    t = eng.tables(logn, qs)
+    ks = F.KeySwitch(eng, t, L, K, dnum)
+    elts = [3, 2 * N - 1, (1 << (logn - 1)) + 1]
+    d0, d1 = eng.upload(c0), eng.upload(c1)
+    prepared = []
+    for k, key in zip(elts, keys):
+        pk = ks.prepare_galois_key(eng.upload(key), k)
+        prepared.append(pk)
+    outs = ks.rotate_hoisted(d0, d1, elts, prepared)
+    for (o0, o1), k, key in zip(outs, elts, keys):
+        w0, w1 = rotate_hoisted_ref(c0, c1, k, key, qs, L, K, dnum, logn)
+        assert (o0.download() == w0).all() and (o1.download() == w1).all(), f"galois element {k}"
+    assert (d0.download() == c0).all() and (d1.download() == c1).all()          # inputs untouched
+    # a second batch on the same plan (buffers reused), one element, and the plain rotation still gives ITS oracle
+    (r0, r1), = ks.rotate_hoisted(d0, d1, elts[1:2], prepared[1:2])
+    w0, w1 = rotate_hoisted_ref(c0, c1, elts[1], keys[1], qs, L, K, dnum, logn)
+    assert (r0.download() == w0).all() and (r1.download() == w1).all()
+    p0, p1 = ks.rotate(d0, d1, elts[0], eng.upload(keys[0]))
+    v0, v1 = rotate_ref(c0, c1, elts[0], keys[0], qs, L, K, dnum, logn)
+    assert (p0.download() == v0).all() and (p1.download() == v1).all()
+    eng.check()
+
+
+def test_prepared_key_is_the_inverse_automorphism_of_the_key(F, eng):
+    from oracle import cport as O
+    from oracle.keyswitch_ref import galois_coeff
+    logn, L, K, dnum, k = 10, 3, 2, 2, 5
+    N = 1 << logn
+    qs, _, _, keys = _rand_case(F, logn, L, K, dnum, 50, 3)
+    t = eng.tables(logn, qs)
+    ks = F.KeySwitch(eng, t, L, K, dnum)
+    got = ks.prepare_galois_key(eng.upload(keys[0]), k).download().reshape(keys[0].shape)
+    kinv = pow(k, -1, 2 * N)
+    for d in range(dnum):
+        for h in range(2):
+            for j, q in enumerate(qs):
+                rp = O.root_powers(q, logn)
+                co = galois_coeff(O.nwt_inverse(keys[0][d, h, j], q, rp), kinv, q)
+                assert (got[d, h, j] == O.nwt_forward(co, q, rp)).all()
+
+
+def _poly_mul(a, b, q, logn):
+    from oracle import cport as O
+    psi = O.min_primitive_root(q, 2 << logn)
+    return O.polymul_ntt(np.asarray(a, dtype=np.uint64), np.asarray(b, dtype=np.uint64), psi, q)
+
+
+def test_hoisted_and_plain_rotation_decrypt_to_the_same_plaintext(F, eng):
+    """decrypt(hoisted rotation) = decrypt(fhe_rotate) = sigma(m) up to key-switch noise, although the ciphertext words differ."""
+    from oracle import cport as O
+    from oracle.keyswitch_ref import galois_coeff
+    logn, N, L, K, dnum = 10, 1024, 4, 2, 2
+    M = L + K
+    qs = F.create_moduli(N, [50] * L + [61] * K)
+    Q, P = qs[:L], qs[L:]
+    Qprod = int(np.prod([int(x) for x in Q], dtype=object))
+    Pprod = int(np.prod([int(x) for x in P], dtype=object))
+    alpha = -(-L // dnum)
+    rnd = random.Random(11)
+    s = [rnd.choice((-1, 0, 1)) for _ in range(N)]
+    rps = [O.root_powers(q, logn) for q in qs]
+    res = lambda v, q: np.array([x % q for x in v], dtype=np.uint64)
+
+    def galois_key(k):
+        sig_s = [0] * N
+        for i, v in enumerate(s):
+            j = (i * k) % (2 * N)
+            if j >= N:
+                sig_s[j - N] = -v
+            else:
+                sig_s[j] = v
+        gk = np.zeros((dnum, 2, M, N), dtype=np.uint64)
+        for d in range(dnum):
+            lo, hi = d * alpha, min(L, (d + 1) * alpha)
+            Qd = int(np.prod([int(x) for x in Q[lo:hi]], dtype=object))
+            Qhat = Qprod // Qd
+            Fd = Pprod * Qhat * pow(Qhat, -1, Qd)
+            e = [rnd.randint(-4, 4) for _ in range(N)]
+            for j, q in enumerate(qs):
+                a = np.array([rnd.randrange(q) for _ in range(N)], dtype=np.uint64)
+                a_s = _poly_mul(a, res(s, q), q, logn)
+                b = (res(e, q).astype(object) - a_s.astype(object) + (Fd % q) * res(sig_s, q).astype(object)) % q
+                gk[d, 0, j] = O.nwt_forward(b.astype(np.uint64), q, rps[j])
+                gk[d, 1, j] = O.nwt_forward(a, q, rps[j])
+        return gk
+
+    m = [rnd.randrange(1 << 30) for _ in range(N)]
+    c1 = np.stack([np.array([rnd.randrange(q) for _ in range(N)], dtype=np.uint64) for q in Q])
+    c0 = np.stack([((res(m, q).astype(object) - _poly_mul(c1[j], res(s, q), q, logn).astype(object)) % q).astype(np.uint64) for j, q in enumerate(Q)])
+    t = eng.tables(logn, qs)
+    ks = F.KeySwitch(eng, t, L, K, dnum)
+    d0 = eng.upload(np.stack([O.nwt_forward(c0[j], Q[j], rps[j]) for j in range(L)]))
+    d1 = eng.upload(np.stack([O.nwt_forward(c1[j], Q[j], rps[j]) for j in range(L)]))
+    elts = [5, 25, 2 * N - 1]
+    gks = [galois_key(k) for k in elts]
+    outs = ks.rotate_hoisted(d0, d1, elts, [ks.prepare_galois_key(eng.upload(g), k) for g, k in zip(gks, elts)])
+    differ = 0
+    for (h0, h1), k, gk in zip(outs, elts, gks):
+        p0, p1 = ks.rotate(d0, d1, k, eng.upload(gk))
+        h0, h1, p0, p1 = h0.download(), h1.download(), p0.download(), p1.download()
+        differ += int((h0 != p0).any() or (h1 != p1).any())
+        want = [int(x) for x in galois_coeff(np.array(m, dtype=np.uint64), k, 1 << 62)]
+        want = [w if w < (1 << 61) else w - (1 << 62) for w in want]
+        for o0, o1 in ((h0, h1), (p0, p1)):
+            q = Q[0]
+            x0 = O.nwt_inverse(o0[0], q, rps[0]).astype(object)
+            x1 = _poly_mul(O.nwt_inverse(o1[0], q, rps[0]), res(s, q), q, logn).astype(object)
+            dec = (x0 + x1) % q
+            worst = 0
+            for i in range(N):
+                diff = (int(dec[i]) - want[i]) % q
+                worst = max(worst, abs(diff - q if diff > q // 2 else diff))
+            assert worst < 16 * N, (k, worst)
+    assert differ == len(elts)      # the two forms are different ciphertexts of the same plaintext (see the module docstring)
+
+
+def test_hoisted_error_statuses(F, eng):
+    from fhe_reliability_gpu_amd._lib import lib, vp
+    logn, L, K, dnum = 10, 3, 1, 3
+    qs, c0, c1, keys = _rand_case(F, logn, L, K, dnum, 50, 9)
+    t = eng.tables(logn, qs)
+    ks = F.KeySwitch(eng, t, L, K, dnum)
+    d0, d1, key = eng.upload(c0), eng.upload(c1), eng.upload(keys[0])
+    with pytest.raises(F.FheError):
+        ks.prepare_galois_key(key, 4)                      # even element
+    pk = ks.prepare_galois_key(key, 3)
+    with pytest.raises(F.FheError):
+        ks.rotate_hoisted(d0, d1, [6], [pk])               # even element
+    # out of place: an output may not be one of the parts
+    o = eng.alloc(L << logn)
+    a0, a1, kk, ge = (vp * 1)(d0.ptr), (vp * 1)(o.ptr), (vp * 1)(pk.ptr), (C.c_uint32 * 1)(3)
+    assert lib.fhe_rotate_hoisted(eng._h, ks._h, a0, a1, d0.ptr, d1.ptr, ge, kk, 1, None) != 0
+    assert b"out of place" in lib.fhe_last_error()
+    # plain rotate: the same contract
+    assert lib.fhe_rotate(eng._h, ks._h, d1.ptr, o.ptr, d0.ptr, d1.ptr, 3, key.ptr, None) != 0
+    # rescale: input and output strides differ, in place is refused
+    parts = eng.upload(np.stack([c0, c1]))
+    assert lib.fhe_rescale(eng._h, ks._h, parts.ptr, parts.ptr, 2, None) != 0
+    assert b"out of place" in lib.fhe_last_error()
+    # an empty batch is a no-op
+    assert lib.fhe_rotate_hoisted(eng._h, ks._h, None, None, d0.ptr, d1.ptr, None, None, 0, None) == 0
+    eng.check()
