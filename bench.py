@@ -551,6 +551,38 @@ def main():
             return out
         also.update(composite_rates())
 
+        def hoisted_rates():
+            # BASELINE configs[4] names a BSGS rotation workload: the baby steps rotate ONE ciphertext by several elements
+            # (profile_framewk/src/matmul_ckks.cpp:45-113).  8 baby rotations at N = 2^16, L = 44, K = 11, dnum = 4: hoisted (one
+            # decomposition, keys in the un-rotated frame) against 8 calls of fhe_rotate; parity: tests/test_gpu_hoisted.py
+            logn, L, K, dnum, n_rot = 16, 44, 11, 4, 8
+            n = 1 << logn
+            qk = F.create_moduli(n, [args.bits] * (L + K))
+            tk = eng.tables(logn, qk)
+            ks = F.KeySwitch(eng, tk, L, K, dnum)
+            mk = lambda *shape: torch.randint(0, qk[0], shape, generator=g, device="cuda", dtype=torch.int64)
+            c0, c1 = mk(L, n), mk(L, n)
+            key = mk(dnum, 2, L + K, n)                      # one key buffer stands for all eight (timing only)
+            outs0 = [torch.empty((L, n), dtype=torch.int64, device="cuda") for _ in range(n_rot)]
+            outs1 = [torch.empty((L, n), dtype=torch.int64, device="cuda") for _ in range(n_rot)]
+            elts = [pow(3, b + 1, 2 * n) for b in range(n_rot)]
+            vp_t = C.c_void_p * n_rot
+            a0, a1 = vp_t(*[x.data_ptr() for x in outs0]), vp_t(*[x.data_ptr() for x in outs1])
+            kk, ge = vp_t(*[key.data_ptr()] * n_rot), (C.c_uint32 * n_rot)(*elts)
+            hoisted = lambda: check(lib.fhe_rotate_hoisted(eng._h, ks._h, a0, a1, P(c0), P(c1), ge, kk, n_rot, sptr))
+
+            def plain():
+                for r in range(n_rot):
+                    check(lib.fhe_rotate(eng._h, ks._h, P(outs0[r]), P(outs1[r]), P(c0), P(c1), elts[r], P(key), sptr))
+            ms_h, ms_p = timed_loop(hoisted, 30, 10), timed_loop(plain, 30, 10)
+            del ks, key
+            return {"hoisted_8_baby_rotations_N=2^16_L44_K11_dnum4": {
+                "us_per_rotation_hoisted": ms_h * 1e3 / n_rot, "us_per_rotation_plain": ms_p * 1e3 / n_rot,
+                "rotations_per_s_hoisted": n_rot / (ms_h * 1e-3), "rotations_per_s_plain": n_rot / (ms_p * 1e-3),
+                "speedup": ms_p / ms_h,
+                "note": "fhe_rotate_hoisted: INTT + digit extension + column pass of the input once, per element the inner product and the mod-down"}}
+        also.update(hoisted_rates())
+
         def fourstep_rate():
             # four_step_ntt (reliability_test/four_step_ntt_prot.py:71-109), MOD = 998244353, as a batch: two launches for all
             # vectors; 2^16 = 256 x 256 and 2^17 = 512 x 256 (the n1 != n2 case of BASELINE configs[3]); 16 N bytes per vector

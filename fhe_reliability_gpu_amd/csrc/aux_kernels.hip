@@ -5,6 +5,7 @@
 #include "ntt_launch.hpp"
 
 #include <cstdlib>
+#include <type_traits>
 
 namespace fhe {
 
@@ -355,47 +356,69 @@ template <int M, class B, int CPT, int OU>
 __device__ __forceinline__ void bc_exact_fixed(const BcJob &job, u64 N, u32 oc)
 {
     typedef typename B::acc_t T;
-    constexpr int OCMAX = 64;
-    __shared__ Tw s_dig[M * M], s_hor[M * OCMAX], s_fpi[M], s_fpo[OCMAX];
-    __shared__ u64 s_pi[M], s_qo[OCMAX];
+    typedef u64 u64x2 __attribute__((ext_vector_type(2)));
+    constexpr int OCMAX = 64, NH = M * M + M + (M + 1) / 2, REC = M + 2;
+    // LDS image = the plan's img_head followed by this workgroup's slice of img_out (ntt_launch.hpp BaseConvPlanDev)
+    __shared__ __attribute__((aligned(16))) Tw s_img[NH + OCMAX * REC];
+    const Tw *s_dig = s_img, *s_fpi = s_img + M * M;
+    const u64 *s_pi = reinterpret_cast<const u64 *>(s_img + M * M + M);
+    const Tw *s_rec = s_img + NH;                         // per output: hor[0..M-1], fp_out, {mod_out, 0}
     const BaseConvPlanDev &pl = job.pl;
-    const u64 *__restrict__ in = job.in;
-    u64 *__restrict__ out = job.out;
+    const u64 FHE_GLOBAL *in = (const u64 FHE_GLOBAL *)job.in;
+    u64 FHE_GLOBAL *out = (u64 FHE_GLOBAL *)job.out;
     const int k = pl.k;
     const u32 FHE_CONSTANT *rows = (const u32 FHE_CONSTANT *)(__UINTPTR_TYPE__)job.in_rows;
-    const Tw FHE_CONSTANT *dig = (const Tw FHE_CONSTANT *)(__UINTPTR_TYPE__)pl.dig, *hor = (const Tw FHE_CONSTANT *)(__UINTPTR_TYPE__)pl.hor;
-    const Tw FHE_CONSTANT *fp_in = (const Tw FHE_CONSTANT *)(__UINTPTR_TYPE__)pl.fp_in, *fp_out = (const Tw FHE_CONSTANT *)(__UINTPTR_TYPE__)pl.fp_out;
-    const u64 FHE_CONSTANT *mod_in = (const u64 FHE_CONSTANT *)(__UINTPTR_TYPE__)pl.mod_in, *mod_out = (const u64 FHE_CONSTANT *)(__UINTPTR_TYPE__)pl.mod_out;
     const int o0 = (int)blockIdx.y * (int)oc, o1 = o0 + (int)oc < k ? o0 + (int)oc : k, cnt = o1 - o0;
     if (cnt <= 0) return;
-    for (int t = threadIdx.x; t < M * M; t += blockDim.x) s_dig[t] = dig[t];                                    // [l][j]
-    for (int t = threadIdx.x; t < M * cnt; t += blockDim.x) s_hor[t] = hor[(t % M) * k + o0 + t / M];          // [o - o0][l]
-    for (int t = threadIdx.x; t < M; t += blockDim.x) {
-        s_fpi[t] = fp_in[t];
-        s_pi[t] = mod_in[t];
-    }
-    for (int t = threadIdx.x; t < cnt; t += blockDim.x) {
-        s_fpo[t] = fp_out[o0 + t];
-        s_qo[t] = mod_out[o0 + t];
-    }
-    __syncthreads();
-    u64 roff[M];      // word offset of input limb j (uniform)
+    // word offset of input limb j (uniform).  One unconditional batch of scalar loads: the plan carries an identity row table for
+    // jobs without a row map (a select per limb put every row's load behind its own branch: eleven dependent trips to the scalar cache,
+    // and the workgroup size read from the dispatch packet one more, before the first residue could be requested)
+    const u32 FHE_CONSTANT *rowtab = rows ? rows : (const u32 FHE_CONSTANT *)(__UINTPTR_TYPE__)pl.rows_identity;
+    u64 roff[M];
 #pragma unroll
-    for (int j = 0; j < M; j++) roff[j] = (rows ? (u64)rows[j] : (u64)j) * N;
-    for (u64 i = (blockIdx.x * (u64)blockDim.x + threadIdx.x) * CPT; i < N; i += (u64)gridDim.x * blockDim.x * CPT) {
-        bc_no_hoist();
-        u64 raw[M][CPT];
+    for (int j = 0; j < M; j++) roff[j] = (u64)rowtab[j] * N;
+    const u64 stride = (u64)gridDim.x * 256 * CPT;            // (launched with 256 threads, launch_fixed_m)
+    u64 i = (blockIdx.x * (u64)256 + threadIdx.x) * CPT;
+    // the first coefficient's residues are requested BEFORE the constants are staged: one trip to memory for both
+    u64 raw[M][CPT];
+    auto load_raw = [&](u64 at) {
 #pragma unroll
         for (int j = 0; j < M; j++) {
-            const u64 *src = in + roff[j] + i;
+            const u64 FHE_GLOBAL *src = in + roff[j] + at;
             if constexpr (CPT == 2) {
-                const ulonglong2 v = *reinterpret_cast<const ulonglong2 *>(src);
+                const u64x2 v = *reinterpret_cast<const u64x2 FHE_GLOBAL *>(src);
                 raw[j][0] = v.x;
                 raw[j][1] = v.y;
             } else {
                 raw[j][0] = *src;
             }
         }
+    };
+    if (i < N) load_raw(i);
+    {
+        // constants: ONE batch of 16-byte requests per thread (round 3's first form staged four tables in four dependent loops:
+        // four trips to memory before the first product)
+        typedef u64x2 FHE_GLOBAL const *gvec;
+        const gvec gh = (gvec)pl.img_head, go = (gvec)pl.img_out + (size_t)o0 * REC;
+        const int total = NH + cnt * REC;
+        constexpr int ROUNDS = (NH + OCMAX * REC + 255) / 256;
+        u64x2 v[ROUNDS];
+#pragma unroll
+        for (int r = 0; r < ROUNDS; r++) {
+            int t = (int)threadIdx.x + r * 256;
+            t = t < total ? t : total - 1;                  // (the tail repeats the last entry: no branch between the requests)
+            v[r] = t < NH ? gh[t] : go[t - NH];
+        }
+#pragma unroll
+        for (int r = 0; r < ROUNDS; r++) {
+            int t = (int)threadIdx.x + r * 256;
+            t = t < total ? t : total - 1;
+            *reinterpret_cast<u64x2 *>(s_img + t) = v[r];
+        }
+    }
+    __syncthreads();
+    for (; i < N; i += stride) {
+        bc_no_hoist();
         // words outside [0, q) (the fault-injection harnesses feed them): ONE cold branch for the whole coefficient
         T x[M][CPT];
         bool bad = false;
@@ -454,23 +477,60 @@ __device__ __forceinline__ void bc_exact_fixed(const BcJob &job, u64 N, u32 oc)
             decltype(B::ctx(0, Tw{})) cxu[OU];
 #pragma unroll
             for (int u = 0; u < OU; u++) {
-                w[0][u] = s_hor[oo[u] * M];
-                cxu[u] = B::ctx(s_qo[oo[u]], s_fpo[oo[u]]);
+                w[0][u] = s_rec[oo[u] * REC];
+                cxu[u] = B::ctx(s_rec[oo[u] * REC + M + 1].a, s_rec[oo[u] * REC + M]);
             }
 #pragma unroll
             for (int l = 0; l < M; l++) {
                 if (l + 1 < M) {
 #pragma unroll
-                    for (int u = 0; u < OU; u++) w[(l + 1) & 1][u] = s_hor[oo[u] * M + l + 1];      // next limb's constants: in flight under this limb's products
+                    for (int u = 0; u < OU; u++) w[(l + 1) & 1][u] = s_rec[oo[u] * REC + l + 1];      // next limb's constants: in flight under this limb's products
                 }
+                if constexpr (std::is_same<B, BcF64>::value) {
+                    // the OU products of this limb step by step, side by side: a product is a chain of five dependent FP64 instructions, and
+                    // written one product after the other a wave has nothing else to issue while each link completes
+                    double h[OU][CPT], kq[OU][CPT], lo[OU][CPT];
 #pragma unroll
-                for (int u = 0; u < OU; u++) {
+                    for (int u = 0; u < OU; u++)
 #pragma unroll
-                    for (int e = 0; e < CPT; e++) {
-                        if (l == 0) acc[u][e] = B::mul(c[0][e], w[0][u], cxu[u]);
-                        else {
-                            acc[u][e] = B::add(acc[u][e], B::mul(c[l][e], w[l & 1][u], cxu[u]), cxu[u]);
-                            B::relax(acc[u][e], l, cxu[u]);
+                        for (int e = 0; e < CPT; e++) h[u][e] = c[l][e] * u64_bits_to_double(w[l & 1][u].a);
+#pragma unroll
+                    for (int u = 0; u < OU; u++)
+#pragma unroll
+                        for (int e = 0; e < CPT; e++) kq[u][e] = c[l][e] * u64_bits_to_double(w[l & 1][u].b);
+#pragma unroll
+                    for (int u = 0; u < OU; u++)
+#pragma unroll
+                        for (int e = 0; e < CPT; e++) kq[u][e] = __builtin_rint(kq[u][e]);
+#pragma unroll
+                    for (int u = 0; u < OU; u++)
+#pragma unroll
+                        for (int e = 0; e < CPT; e++) lo[u][e] = __builtin_fma(c[l][e], u64_bits_to_double(w[l & 1][u].a), -h[u][e]);
+#pragma unroll
+                    for (int u = 0; u < OU; u++)
+#pragma unroll
+                        for (int e = 0; e < CPT; e++) h[u][e] = __builtin_fma(-kq[u][e], cxu[u].n, h[u][e]);
+#pragma unroll
+                    for (int u = 0; u < OU; u++)
+#pragma unroll
+                        for (int e = 0; e < CPT; e++) h[u][e] += lo[u][e];
+#pragma unroll
+                    for (int u = 0; u < OU; u++)
+#pragma unroll
+                        for (int e = 0; e < CPT; e++) {
+                            acc[u][e] = l == 0 ? h[u][e] : acc[u][e] + h[u][e];
+                            if (l) B::relax(acc[u][e], l, cxu[u]);
+                        }
+                } else {
+#pragma unroll
+                    for (int u = 0; u < OU; u++) {
+#pragma unroll
+                        for (int e = 0; e < CPT; e++) {
+                            if (l == 0) acc[u][e] = B::mul(c[0][e], w[0][u], cxu[u]);
+                            else {
+                                acc[u][e] = B::add(acc[u][e], B::mul(c[l][e], w[l & 1][u], cxu[u]), cxu[u]);
+                                B::relax(acc[u][e], l, cxu[u]);
+                            }
                         }
                     }
                 }
@@ -481,11 +541,12 @@ __device__ __forceinline__ void bc_exact_fixed(const BcJob &job, u64 N, u32 oc)
 #pragma unroll
             for (int u = 0; u < OU; u++) {
                 const int o = o0 + oo[u];
-                u64 *dst = out + (u64)((u32)o < job.gap_at ? o : o + job.gap) * N + i;
-                if constexpr (CPT == 2) *reinterpret_cast<ulonglong2 *>(dst) = ulonglong2{B::out(acc[u][0], cxu[u]), B::out(acc[u][1], cxu[u])};
+                u64 FHE_GLOBAL *dst = out + (u64)((u32)o < job.gap_at ? o : o + job.gap) * N + i;
+                if constexpr (CPT == 2) *reinterpret_cast<u64x2 FHE_GLOBAL *>(dst) = u64x2{B::out(acc[u][0], cxu[u]), B::out(acc[u][1], cxu[u])};
                 else *dst = B::out(acc[u][0], cxu[u]);
             }
         }
+        if (i + stride < N) load_raw(i + stride);       // (grids cover N in one step except for N beyond 2^22)
     }
 }
 
@@ -545,7 +606,7 @@ static u32 bc_slices(u32 gx, u32 jobs, int m, int k, u32 target = 2048)
     return slices;
 }
 
-// tuning knobs of the fixed-size form (read once): FHE_BC_VARIANT = CPT * 10 + OU (0 = the runtime-m kernels), FHE_BC_WGS = workgroups to aim at
+// tuning knobs of the fixed-size form (read once): FHE_BC_VARIANT = 0 selects the runtime-m kernels, FHE_BC_WGS = workgroups to aim at
 static int bc_env(const char *name, int dflt)
 {
     const char *v = getenv(name);
@@ -565,28 +626,27 @@ static void launch_fixed_m(hipStream_t st, dim3 grid, const BcJob *dev_jobs, con
 }
 
 // m_mask: bit (m - 1) set for every input size present among the jobs (one launch per size; a launch's workgroups of the other
-// sizes leave at once)
+// sizes leave at once).  One coefficient per thread; four outputs side by side where the digits leave room for it in 128 registers
+// (two coefficients per thread measured 10 % slower at N = 2^16, L = 44: half the workgroups, or the digits computed twice).
 template <class B>
 static void launch_fixed(hipStream_t st, const BcJob *dev_jobs, const BcJob &job, u32 n_jobs, u32 m_mask, int max_k, u64 N)
 {
-    static const int variant = bc_env("FHE_BC_VARIANT", 14), target = bc_env("FHE_BC_WGS", 1024);
-    int cpt = variant / 10, ou = variant % 10;
-    if (N & 1) cpt = 1;
+    static const int target = bc_env("FHE_BC_WGS", 1024);
     for (int m = 1; m <= 16; m++) {
         if (!((m_mask >> (m - 1)) & 1)) continue;
-        const u64 want = (N / cpt + 255) / 256;
+        const u64 want = (N + 255) / 256;
         const u32 gx = (u32)(want > 16384 ? 16384 : want);
         const u32 slices = bc_slices(gx, n_jobs, m, max_k, (u32)target), oc = ((u32)max_k + slices - 1) / slices;
         const dim3 grid(gx, ((u32)max_k + oc - 1) / oc, n_jobs);
-        if (cpt == 2 && ou == 4) launch_fixed_m<B, 2, 4>(st, grid, dev_jobs, job, m, N, oc);
-        else if (cpt == 2) launch_fixed_m<B, 2, 2>(st, grid, dev_jobs, job, m, N, oc);
-        else if (ou == 4) launch_fixed_m<B, 1, 4>(st, grid, dev_jobs, job, m, N, oc);
+        const bool wide = std::is_same<B, BcF64>::value ? m <= 14 : m <= 11;
+        if (wide) launch_fixed_m<B, 1, 4>(st, grid, dev_jobs, job, m, N, oc);
         else launch_fixed_m<B, 1, 2>(st, grid, dev_jobs, job, m, N, oc);
     }
 }
+// FHE_BC_VARIANT=0: the runtime-m kernels everywhere (A/B runs)
 static bool bc_fixed_on()
 {
-    static const int variant = bc_env("FHE_BC_VARIANT", 14);
+    static const int variant = bc_env("FHE_BC_VARIANT", 1);
     return variant != 0;
 }
 
@@ -844,6 +904,47 @@ hipError_t launch_tensor(hipStream_t st, const TensorArgs &p)
     if (!total) return hipSuccess;
     const u64 want = (total + 255) / 256;
     hipLaunchKernelGGL(k_tensor, dim3((u32)(want > 16384 ? 16384 : want)), dim3(256), 0, st, p);
+    return hipGetLastError();
+}
+
+// ---------------------------------------------------------------------------
+// Inner sum of a baby-step / giant-step matrix-vector product (profile_framewk/src/matmul_ckks.cpp:45-113, multiply_plain + add over
+// the baby steps; motivation/bsgs.py:44-51 is the same accumulate on plaintext blocks): for both parts h of the rotated ciphertexts
+//   out_h[l][i] = sum_{b < n1} diag[b][l][i] * R_b,h[l][i]  mod q_l,      R_0 = (x0, x1), R_b = rot[b-1] for b >= 1
+// one pass: every diagonal and every rotated part is read once, the sums stay in registers (lazy, reduced every eighth term).
+// ---------------------------------------------------------------------------
+template <class K>
+__device__ __forceinline__ void diag_mac_elem(const DiagMacArgs &a, u64 e, const LimbParams &p)
+{
+    const u64 part = (u64)a.limbs << a.logn;
+    typename K::acc_t s0 = K::zero(), s1 = K::zero();
+    for (u32 b = 0; b < a.n1; b++) {
+        const u64 d = a.diag[(u64)b * part + e];
+        const u64 *r = b ? a.rot + (u64)(b - 1) * 2 * part : nullptr;
+        const u64 y0 = b ? r[e] : a.x0[e], y1 = b ? r[part + e] : a.x1[e];
+        K::mac(s0, d, y0, (int)b, p);
+        K::mac(s1, d, y1, (int)b, p);
+    }
+    a.out0[e] = K::out(s0, p);
+    a.out1[e] = K::out(s1, p);
+}
+
+__global__ __launch_bounds__(256) void k_diag_mac(DiagMacArgs a)
+{
+    const u64 total = (u64)a.limbs << a.logn;
+    for (u64 e = blockIdx.x * (u64)blockDim.x + threadIdx.x; e < total; e += (u64)gridDim.x * blockDim.x) {
+        const LimbParams &p = a.lp[a.limb0 + (u32)(e >> a.logn)];
+        if (p.path == PATH_F64) diag_mac_elem<KsMacF64>(a, e, p);
+        else diag_mac_elem<KsMacU64>(a, e, p);
+    }
+}
+
+hipError_t launch_diag_mac(hipStream_t st, const DiagMacArgs &a)
+{
+    const u64 total = (u64)a.limbs << a.logn;
+    if (!total || !a.n1) return hipSuccess;
+    const u64 want = (total + 255) / 256;
+    hipLaunchKernelGGL(k_diag_mac, dim3((u32)(want > 16384 ? 16384 : want)), dim3(256), 0, st, a);
     return hipGetLastError();
 }
 

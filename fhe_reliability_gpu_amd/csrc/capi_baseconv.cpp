@@ -72,8 +72,27 @@ int fhe_baseconv_create(fhe_ctx *ctx, const uint64_t *mod_in, int m, const uint6
     HIP_TRY(p->fp_out.upload(fpo));
     HIP_TRY(p->fast_coef.upload(fc));
     HIP_TRY(p->fast_shoup.upload(fs));
+    if (m <= 16) {
+        std::vector<Tw> head((size_t)m * m + m + (m + 1) / 2, Tw{0, 0}), outs((size_t)k * (m + 2), Tw{0, 0});
+        for (int i = 0; i < m * m; i++) head[i] = dig[i];
+        for (int j = 0; j < m; j++) {
+            head[(size_t)m * m + j] = fpi[j];
+            Tw &e = head[(size_t)m * m + m + j / 2];
+            (j & 1 ? e.b : e.a) = mi[j];
+        }
+        for (int o = 0; o < k; o++) {
+            for (int l = 0; l < m; l++) outs[(size_t)o * (m + 2) + l] = hor[(size_t)l * k + o];
+            outs[(size_t)o * (m + 2) + m] = fpo[o];
+            outs[(size_t)o * (m + 2) + m + 1] = Tw{mo[o], 0};
+        }
+        HIP_TRY(p->img_head.upload(head));
+        HIP_TRY(p->img_out.upload(outs));
+        std::vector<u32> ident(64);
+        for (u32 i = 0; i < 64; i++) ident[i] = i;
+        HIP_TRY(p->rows_id.upload(ident));
+    }
     p->dev = BaseConvPlanDev{m, k, p->mod_in.as<u64>(), p->mod_out.as<u64>(), p->dig.as<Tw>(), p->hor.as<Tw>(), p->fp_in.as<Tw>(),
-                             p->fp_out.as<Tw>(), f64 ? 1 : 0, p->fast_coef.as<u64>(), p->fast_shoup.as<u64>()};
+                             p->fp_out.as<Tw>(), f64 ? 1 : 0, p->fast_coef.as<u64>(), p->fast_shoup.as<u64>(), p->img_head.as<Tw>(), p->img_out.as<Tw>(), p->rows_id.as<u32>()};
     *out = p.release();
     return FHE_OK;
 }

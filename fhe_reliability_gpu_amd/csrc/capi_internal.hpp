@@ -81,7 +81,7 @@ struct fhe_ntt_tables {
 struct fhe_baseconv {
     int m = 0, k = 0;
     bool fast_ok = true;
-    DevBuf mod_in, mod_out, dig, hor, fp_in, fp_out, fast_coef, fast_shoup;
+    DevBuf mod_in, mod_out, dig, hor, fp_in, fp_out, fast_coef, fast_shoup, img_head, img_out, rows_id;
     BaseConvPlanDev dev{};
 };
 
@@ -184,6 +184,7 @@ struct fhe_keyswitch {
     DevBuf qlast_inv;                  // q_{L-1}^-1 mod q_j, owned j < L-1
     DevBuf rs_last, rs_delta, rs_jobs; // rs_last backs rs_bc on one device; [3][rs_n][N] residues; job list (3 parts)
     DevBuf hm, hm_pre;                 // [3][L][N] tensor product, [2][L][N] relinearised product before the rescale
+    DevBuf bsgs;                       // fhe_bsgs_matvec: baby rotations, inner sum, one rotated inner sum (grown on demand)
     DevBuf hsp, hdown_rows, hdown_jobs; // hoisted rotations (allocated on first use): [2][K][N] special limbs of sigma(sums) in coefficient form, the mod-down jobs that read them
     u64 t_inv_qlast = 0;               // plain_modulus^-1 mod q_{L-1} (BGV)
     ~fhe_keyswitch()

@@ -651,6 +651,54 @@ extern "C" int fhe_rotate_hoisted(fhe_ctx *ctx, fhe_keyswitch *p, uint64_t *cons
     return FHE_OK;
 }
 
+// ---------------------------------------------------------------- baby-step / giant-step matrix-vector product
+// y = sum_{g < n2} sigma_{G_g}( sum_{b < n1} diag[g][b] * sigma_{B_b}(x) ),  sigma_{B_0} = sigma_{G_0} = identity
+// (profile_framewk/src/matmul_ckks.cpp:45-113 in the arrangement that needs n1 + n2 - 2 rotations instead of n1 n2 - 1; its plaintext
+// block form is motivation/bsgs.py:39-52): the n1 - 1 baby rotations of x are HOISTED (one decomposition of x), the n2 inner sums are one
+// launch each (k_diag_mac), the n2 - 1 giant rotations are plain rotations of the inner sums, accumulated into the result.
+extern "C" int fhe_bsgs_matvec(fhe_ctx *ctx, fhe_keyswitch *p, uint64_t *d_out0, uint64_t *d_out1, const uint64_t *d_c0, const uint64_t *d_c1,
+                               const uint64_t *d_diags, size_t n1, size_t n2, const uint32_t *baby_elts, const uint64_t *const *d_baby_keys_prepared,
+                               const uint32_t *giant_elts, const uint64_t *const *d_giant_keys, void *stream)
+{
+    if (!ctx || !p || !d_out0 || !d_out1 || !d_c0 || !d_c1 || !d_diags || n1 < 1 || n2 < 1 || n1 > 4096 || n2 > 4096) return fail(FHE_ERR_INVALID, "bad arguments");
+    if ((n1 > 1 && (!baby_elts || !d_baby_keys_prepared)) || (n2 > 1 && (!giant_elts || !d_giant_keys))) return fail(FHE_ERR_INVALID, "null argument");
+    if (d_out0 == d_c0 || d_out0 == d_c1 || d_out1 == d_c0 || d_out1 == d_c1 || d_out0 == d_out1) return fail(FHE_ERR_INVALID, "the product is out of place");
+    if (p->sharded) return fail(FHE_ERR_UNSUPPORTED, "the BSGS product runs on one device");
+    HIP_TRY(hipSetDevice(ctx->device));
+    hipStream_t st = pick(ctx, stream);
+    const fhe_ntt_tables *t = p->t;
+    const size_t N = (size_t)1 << p->log_n, L = p->L, part = L * N;
+    // scratch: baby rotations [n1 - 1][2][L][N], inner sum [2][L][N], one rotated inner sum [2][L][N]
+    const size_t need = ((n1 - 1) * 2 + 4) * part * 8;
+    if (p->bsgs.bytes < need) {
+        HIP_TRY(hipStreamSynchronize(st));        // (growing frees the old block)
+        HIP_TRY(p->bsgs.alloc(need));
+    }
+    u64 *rot = p->bsgs.as<u64>(), *inner = rot + (n1 - 1) * 2 * part, *tmp = inner + 2 * part;
+    int rc;
+    if (n1 > 1) {
+        std::vector<u64 *> o0(n1 - 1), o1(n1 - 1);
+        for (size_t b = 1; b < n1; b++) {
+            o0[b - 1] = rot + (b - 1) * 2 * part;
+            o1[b - 1] = o0[b - 1] + part;
+        }
+        if ((rc = fhe_rotate_hoisted(ctx, p, o0.data(), o1.data(), d_c0, d_c1, baby_elts, d_baby_keys_prepared, n1 - 1, stream))) return rc;
+    }
+    const LimbParams *lp = t->d_lp.as<LimbParams>();
+    for (size_t g = 0; g < n2; g++) {
+        // inner sum of giant step g: straight into the result for g = 0
+        u64 *s0 = g ? inner : d_out0, *s1 = g ? inner + part : d_out1;
+        const DiagMacArgs da{s0, s1, d_diags + g * n1 * part, d_c0, d_c1, rot, lp, 0u, (u32)L, (u32)n1, p->log_n};
+        hipError_t e = launch_diag_mac(st, da);
+        if (e != hipSuccess) return hip_fail(e, "launch_diag_mac");
+        if (!g) continue;
+        if ((rc = fhe_rotate(ctx, p, tmp, tmp + part, inner, inner + part, giant_elts[g - 1], d_giant_keys[g - 1], stream))) return rc;
+        if ((rc = fhe_modadd(ctx, d_out0, d_out0, tmp, t, 1, L, 0, stream))) return rc;
+        if ((rc = fhe_modadd(ctx, d_out1, d_out1, tmp + part, t, 1, L, 0, stream))) return rc;
+    }
+    return FHE_OK;
+}
+
 // The three phases of a rotation on a limb-sharded plan (the joins between them are the key switch's, fhe_keyswitch_shard_*): the
 // automorphism permutes slots inside each limb, so every rank applies it to its own rows -- on the loads of its launches.
 int fhe_rotate_shard_begin(fhe_ctx *ctx, fhe_keyswitch *p, const uint64_t *d_c1_local, uint32_t galois_elt, void *stream)

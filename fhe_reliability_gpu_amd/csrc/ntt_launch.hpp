@@ -102,6 +102,16 @@ struct TensorArgs {
     int logn;
 };
 hipError_t launch_tensor(hipStream_t st, const TensorArgs &p);
+// inner sum of a BSGS matrix-vector product: out_h = sum_b diag[b] * R_b,h per limb (aux_kernels.hip k_diag_mac); diag = [n1][limbs][N],
+// R_0 = (x0, x1), R_b = rot + (b - 1) * 2 * limbs * N ([n1 - 1][2][limbs][N])
+struct DiagMacArgs {
+    u64 *out0, *out1;
+    const u64 *diag, *x0, *x1, *rot;
+    const LimbParams *lp;
+    u32 limb0, limbs, n1;
+    int logn;
+};
+hipError_t launch_diag_mac(hipStream_t st, const DiagMacArgs &a);
 hipError_t launch_modadd(hipStream_t st, const PointwiseArgs &p);
 hipError_t launch_modsub(hipStream_t st, const PointwiseArgs &p);
 constexpr int SCALAR_MAX_LIMBS = 64;
@@ -159,6 +169,12 @@ struct BaseConvPlanDev {
     int f64;                  // 1: every modulus < 2^50, constants encoded for ArithF64; 0: Shoup pairs (ArithU64)
     const u64 *fast_coef;     // m x k   (Phat_j * inv_j) mod q_o   (rfhe_framewk/src/baseConv.py:17-29)
     const u64 *fast_coef_shoup;
+    // m <= 16: the same constants laid out as the fixed-size kernels keep them in LDS, so that a workgroup stages them with ONE batch
+    // of 16-byte loads: img_head = dig [m][m], fp_in [m], mod_in [m] (two per entry); img_out = per output o: hor[0..m-1][o], fp_out[o],
+    // {mod_out[o], 0} -- m + 2 entries per output, a slice of outputs is a contiguous range
+    const Tw *img_head;
+    const Tw *img_out;
+    const u32 *rows_identity; // 0, 1, 2, ... (64 entries): the row map of a job that has none
 };
 // output limb o is written at limb index o (o < gap_at) or o + gap: lets a key-switch digit's extension land
 // in the [M][N] layout with the digit's own limbs skipped

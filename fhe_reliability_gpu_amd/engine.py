@@ -469,6 +469,17 @@ class KeySwitch:
         check(lib.fhe_rotate_hoisted(self.eng._h, self._h, a0, a1, c0.ptr, c1.ptr, ge, ks, n, stream))
         return outs
 
+    def bsgs_matvec(self, c0: DeviceArray, c1: DeviceArray, diags: DeviceArray, n1: int, n2: int, baby_elts, baby_keys_prepared,
+                    giant_elts, giant_keys, stream=None):
+        """Baby-step / giant-step matrix-vector product (profile_framewk/src/matmul_ckks.cpp:45-113): diags = [n2][n1][L][N]."""
+        o0, o1 = self._out(self.L), self._out(self.L)
+        be = (C.c_uint32 * max(1, n1 - 1))(*[int(g) for g in baby_elts])
+        ge = (C.c_uint32 * max(1, n2 - 1))(*[int(g) for g in giant_elts])
+        bk = (vp * max(1, n1 - 1))(*[k.ptr for k in baby_keys_prepared])
+        gk = (vp * max(1, n2 - 1))(*[k.ptr for k in giant_keys])
+        check(lib.fhe_bsgs_matvec(self.eng._h, self._h, o0.ptr, o1.ptr, c0.ptr, c1.ptr, diags.ptr, n1, n2, be, bk, ge, gk, stream))
+        return o0, o1
+
     def set_plain_modulus(self, t: int):
         """BGV form of the mod-down and of the rescale (0 = CKKS-style flooring)."""
         check(lib.fhe_keyswitch_set_plain_modulus(self._h, t))

@@ -280,6 +280,18 @@ int fhe_rotate(fhe_ctx *ctx, fhe_keyswitch *p, uint64_t *d_out0, uint64_t *d_out
 int fhe_galois_key_prepare(fhe_ctx *ctx, fhe_keyswitch *p, uint64_t *d_key_out, const uint64_t *d_key_in, uint32_t galois_elt, void *stream);
 int fhe_rotate_hoisted(fhe_ctx *ctx, fhe_keyswitch *p, uint64_t *const *d_out0, uint64_t *const *d_out1, const uint64_t *d_c0,
                        const uint64_t *d_c1, const uint32_t *galois_elts, const uint64_t *const *d_prepared_keys, size_t n_rot, void *stream);
+/* Baby-step / giant-step matrix-vector product on a two-part ciphertext x = (c0, c1) (profile_framewk/src/matmul_ckks.cpp:45-113 --
+ * rotate, multiply_plain with a diagonal, add -- in the arrangement with n1 + n2 - 2 rotations; plaintext block form:
+ * motivation/bsgs.py:39-52):
+ *     y = sum_{g < n2} sigma_{giant_elts[g-1]}( sum_{b < n1} diag[g][b] (.) sigma_{baby_elts[b-1]}(x) ),   g = 0 and b = 0: no rotation.
+ * d_diags = [n2][n1][L][N] NTT-form plaintext polynomials (the caller pre-rotates the diagonals of giant step g by -g n1, as BSGS
+ * requires); baby keys in the un-rotated frame (fhe_galois_key_prepare), giant keys as fhe_rotate takes them; baby_elts / the key
+ * arrays have n1 - 1 resp. n2 - 1 entries (host arrays).  The n1 - 1 baby rotations share one decomposition of x
+ * (fhe_rotate_hoisted), each inner sum is one launch, the giant rotations are fhe_rotate calls accumulated into (d_out0, d_out1).
+ * No rescale inside (apply fhe_rescale to the result).  Out of place; one device. */
+int fhe_bsgs_matvec(fhe_ctx *ctx, fhe_keyswitch *p, uint64_t *d_out0, uint64_t *d_out1, const uint64_t *d_c0, const uint64_t *d_c1,
+                    const uint64_t *d_diags, size_t n1, size_t n2, const uint32_t *baby_elts, const uint64_t *const *d_baby_keys_prepared,
+                    const uint32_t *giant_elts, const uint64_t *const *d_giant_keys, void *stream);
 /* The same rotation on a limb-sharded plan (fhe_keyswitch_create_sharded): the automorphism permutes slots inside a limb, so each
  * rank applies it to its own rows -- on the loads of the launches below, there is no permuted copy of c0 and no launch for it.
  * Phases and joins as for the sharded key switch:

@@ -73,7 +73,28 @@ def lib() -> C.CDLL:
             f = getattr(L, name)
             f.restype, f.argtypes = res, args
         _lib = L
+        # OpenMP would start one worker per visible CPU; a GPU box shows 256 of them to a job that may use 16 (cgroup quota), and every
+        # parallel region of the batch helpers then costs milliseconds of oversubscription (a rotate_ref at N = 32 took 2.8 s there):
+        # default to the cores this process may really use
+        if "OMP_NUM_THREADS" not in os.environ:
+            L.orc_set_threads(_usable_cores())
     return _lib
+
+
+def _usable_cores() -> int:
+    n = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
+    try:
+        quota, period = open("/sys/fs/cgroup/cpu.max").read().split()[:2]
+        if quota != "max":
+            n = min(n, max(1, int(float(quota) / float(period) + 0.5)))
+    except Exception:
+        try:
+            q = int(open("/sys/fs/cgroup/cpu/cpu.cfs_quota_us").read())
+            if q > 0:
+                n = min(n, max(1, int(q / int(open("/sys/fs/cgroup/cpu/cpu.cfs_period_us").read()) + 0.5)))
+        except Exception:
+            pass
+    return max(1, min(n, 32))
 
 
 def _a(x) -> np.ndarray:

@@ -109,6 +109,33 @@ def rotate_hoisted_ref(c0, c1, k, gk, qs, L, K, dnum, logn):
     return keyswitch_ref(c1, gk, qs, L, K, dnum, logn, add0=sig0, rps=rps, sigma_ext=k)
 
 
+def bsgs_matvec_ref(c0, c1, diags, baby_elts, baby_keys, giant_elts, giant_keys, qs, L, K, dnum, logn):
+    """fhe_bsgs_matvec: y = sum_g sigma_G_g( sum_b diag[g][b] * sigma_B_b(x) ) (profile_framewk/src/matmul_ckks.cpp:45-113, the
+    rotate / multiply_plain / add sequence in the n1 + n2 - 2 arrangement).  diags: (n2, n1, L, N); baby rotations hoisted
+    (rotate_hoisted_ref), giant ones plain (rotate_ref); keys in their standard form."""
+    n2, n1 = diags.shape[0], diags.shape[1]
+    Q = [int(q) for q in qs[:L]]
+    R = [(np.asarray(c0, dtype=np.uint64), np.asarray(c1, dtype=np.uint64))]
+    for b in range(1, n1):
+        R.append(rotate_hoisted_ref(c0, c1, baby_elts[b - 1], baby_keys[b - 1], qs, L, K, dnum, logn))
+    y = None
+    for g in range(n2):
+        inner = []
+        for h in range(2):
+            s = None
+            for b in range(n1):
+                s = O.modmul_batch(diags[g, b], R[b][h], Q, acc=s)
+            inner.append(s)
+        if g:
+            inner = rotate_ref(inner[0], inner[1], giant_elts[g - 1], giant_keys[g - 1], qs, L, K, dnum, logn)
+        if y is None:
+            y = [inner[0].copy(), inner[1].copy()]
+        else:
+            for h in range(2):
+                y[h] = np.stack([(y[h][l] + inner[h][l]) % np.uint64(Q[l]) for l in range(L)])
+    return y[0], y[1]
+
+
 def tensor_ref(a0, a1, b0, b1, qs):
     """MULTIPLY_CKKS (16384_4:388-389 / multiply, dotprod_test.cu:113), NTT domain, per limb."""
     L = a0.shape[0]

@@ -181,3 +181,66 @@ def test_hoisted_error_statuses(F, eng):
     # an empty batch is a no-op
     assert lib.fhe_rotate_hoisted(eng._h, ks._h, None, None, d0.ptr, d1.ptr, None, None, 0, None) == 0
     eng.check()
+
+
+@pytest.mark.parametrize("logn,L,K,dnum,n1,n2", [(10, 3, 1, 3, 3, 2), (13, 4, 2, 2, 2, 3), (12, 3, 1, 1, 4, 1), (13, 3, 1, 3, 1, 2)])
+def test_bsgs_matvec_matches_oracle_composite(F, eng, logn, L, K, dnum, n1, n2):
+    """fhe_bsgs_matvec (hoisted baby rotations, one launch per inner sum, giant rotations accumulated) word for word against the oracle's
+    rotate / multiply_plain / add sequence (profile_framewk/src/matmul_ckks.cpp:45-113)."""
+    from oracle.keyswitch_ref import bsgs_matvec_ref
+    N = 1 << logn
+    qs = F.create_moduli(N, [50] * (L + K))
+    t = eng.tables(logn, qs)
+    rng = np.random.default_rng(logn + n1 * 10 + n2)
+    mk = lambda rows: np.stack([rng.integers(0, q, N, dtype=np.uint64) for q in qs[:rows]])
+    key = lambda: np.stack([np.stack([mk(L + K) for _ in range(2)]) for _ in range(dnum)])
+    c0, c1 = mk(L), mk(L)
+    diags = np.stack([np.stack([mk(L) for _ in range(n1)]) for _ in range(n2)])
+    baby_elts = [pow(3, b, 2 * N) for b in range(1, n1)]
+    giant_elts = [pow(3, g * n1, 2 * N) for g in range(1, n2)]
+    baby_keys, giant_keys = [key() for _ in baby_elts], [key() for _ in giant_elts]
+    ks = F.KeySwitch(eng, t, L, K, dnum)
+    prepared = [ks.prepare_galois_key(eng.upload(k), e) for k, e in zip(baby_keys, baby_elts)]
+    o0, o1 = ks.bsgs_matvec(eng.upload(c0), eng.upload(c1), eng.upload(diags), n1, n2, baby_elts, prepared, giant_elts, [eng.upload(k) for k in giant_keys])
+    w0, w1 = bsgs_matvec_ref(c0, c1, diags, baby_elts, baby_keys, giant_elts, giant_keys, qs, L, K, dnum, logn)
+    assert (o0.download() == w0).all() and (o1.download() == w1).all()
+    eng.check()
+
+
+def test_bsgs_matvec_on_a_trivial_ciphertext_is_the_plaintext_formula(F, eng):
+    """x = (m, 0): a key switch of the zero polynomial is exactly zero, so every rotation is exact and the product must equal
+    sum_g sigma_G( sum_b diag[g][b] * sigma_B(m) ) computed with plain polynomial automorphisms -- the structure of
+    motivation/bsgs.py:39-52 / matmul_ckks.cpp:45-113 checked without going through the key-switch oracle."""
+    from oracle import cport as O
+    from oracle.keyswitch_ref import galois_coeff
+    logn, L, K, dnum, n1, n2 = 11, 3, 1, 3, 3, 3
+    N = 1 << logn
+    qs = F.create_moduli(N, [50] * (L + K))
+    Q = qs[:L]
+    t = eng.tables(logn, qs)
+    rng = np.random.default_rng(5)
+    mk = lambda rows: np.stack([rng.integers(0, q, N, dtype=np.uint64) for q in qs[:rows]])
+    key = lambda: np.stack([np.stack([mk(L + K) for _ in range(2)]) for _ in range(dnum)])
+    rps = [O.root_powers(q, logn) for q in Q]
+    m = mk(L)                                                   # NTT form
+    diags = np.stack([np.stack([mk(L) for _ in range(n1)]) for _ in range(n2)])
+    baby_elts = [pow(5, b, 2 * N) for b in range(1, n1)]
+    giant_elts = [pow(5, g * n1, 2 * N) for g in range(1, n2)]
+    ks = F.KeySwitch(eng, t, L, K, dnum)
+    prepared = [ks.prepare_galois_key(eng.upload(key()), e) for e in baby_elts]
+    zero = eng.upload(np.zeros((L, N), dtype=np.uint64))
+    o0, o1 = ks.bsgs_matvec(eng.upload(m), zero, eng.upload(diags), n1, n2, baby_elts, prepared, giant_elts, [eng.upload(key()) for _ in giant_elts])
+
+    def sigma(x, k):                                            # NTT form -> NTT form
+        return np.stack([O.nwt_forward(galois_coeff(O.nwt_inverse(x[l], Q[l], rps[l]), k, Q[l]), Q[l], rps[l]) for l in range(L)])
+    want = np.zeros((L, N), dtype=np.uint64)
+    for g in range(n2):
+        inner = None
+        for b in range(n1):
+            inner = O.modmul_batch(diags[g, b], m if b == 0 else sigma(m, baby_elts[b - 1]), Q, acc=inner)
+        if g:
+            inner = sigma(inner, giant_elts[g - 1])
+        want = np.stack([(want[l] + inner[l]) % np.uint64(Q[l]) for l in range(L)])
+    assert (o0.download() == want).all()
+    assert not o1.download().any()
+    eng.check()
