@@ -302,3 +302,85 @@ def test_config4_hmult_full_shape(F, eng, dnum):
     assert g0.shape == (L - 1, N) and g1.shape == (L - 1, N)
     bad = [(h, j) for h, (g, w) in enumerate(((g0, w0), (g1, w1))) for j in range(L - 1) if not (g[j] == w[j]).all()]
     assert not bad, f"limbs that differ from the oracle (part, limb): {bad[:8]}"
+
+
+# ------------------------------------------------------------------ round 3: hoisted baby steps at the config-5 shape
+def test_config5_hoisted_rotations_full_shape(F, eng):
+    """BASELINE configs[4] names a BSGS rotation workload: three baby rotations of ONE ciphertext at N = 2^16, L = 44, K = 11, dnum = 4
+    with the decomposition shared (fhe_rotate_hoisted), every limb of every output against the oracle composite
+    (oracle/keyswitch_ref.py rotate_hoisted_ref; profile_framewk/src/matmul_ckks.cpp:45-113 for the workload)."""
+    from oracle.keyswitch_ref import rotate_hoisted_ref
+    logn, L, K, dnum = 16, 44, 11, 4
+    N = 1 << logn
+    qs = F.create_moduli(N, [50] * (L + K))
+    t = eng.tables(logn, qs)
+    rng = np.random.default_rng(2025)
+    c0, c1 = _limbs(rng, qs[:L], N), _limbs(rng, qs[:L], N)
+    elts = [3, 9, 2 * N - 1]
+    keys = [_key(rng, qs, dnum, N) for _ in elts[:2]]
+    keys.append(keys[0])                                   # (a third element on the first key's words: the arithmetic does not care)
+    ks = F.KeySwitch(eng, t, L, K, dnum)
+    prepared = [ks.prepare_galois_key(eng.upload(k), e) for k, e in zip(keys, elts)]
+    outs = ks.rotate_hoisted(eng.upload(c0), eng.upload(c1), elts, prepared)
+    for (o0, o1), e, k in zip(outs, elts, keys):
+        w0, w1 = rotate_hoisted_ref(c0, c1, e, k, qs, L, K, dnum, logn)
+        assert (o0.download() == w0).all() and (o1.download() == w1).all(), f"galois element {e}"
+    eng.check()
+
+
+def test_rescale_error_is_bounded_at_the_decryption_level(F, eng):
+    """fhe_rescale floors: c' = (c - [c]_q_last) / q_last exactly, so for a ciphertext (c0, c1) with c0 + c1 s = m (mod Q):
+    c0' + c1' s = (m - ([c0] + [c1] s)) / q_last, i.e. the scaled plaintext up to (1 + |s|_1) in absolute value.  SEAL / Phantom round
+    instead of flooring: this test pins the engine's choice, a later switch would change the bound's centre."""
+    from oracle import cport as O
+    logn, N, L, K = 10, 1024, 4, 1
+    qs = F.create_moduli(N, [50] * (L + K))
+    Q = qs[:L]
+    ql = Q[-1]
+    rnd = random.Random(3)
+    s = [rnd.choice((-1, 0, 1)) for _ in range(N)]
+    rps = [O.root_powers(q, logn) for q in Q]
+    res = lambda v, q: np.array([x % q for x in v], dtype=np.uint64)
+    psi = [O.min_primitive_root(q, 2 * N) for q in Q]
+    big_m = [rnd.randrange(-(1 << 120), 1 << 120) for _ in range(N)]
+    c1 = np.stack([np.array([rnd.randrange(q) for _ in range(N)], dtype=np.uint64) for q in Q])
+    c0 = np.stack([((res(big_m, q).astype(object) - O.polymul_ntt(c1[j], res(s, q), psi[j], q).astype(object)) % q).astype(np.uint64) for j, q in enumerate(Q)])
+    t = eng.tables(logn, qs)
+    ks = F.KeySwitch(eng, t, L, K, L)
+    parts = np.stack([np.stack([O.nwt_forward(c[j], Q[j], rps[j]) for j in range(L)]) for c in (c0, c1)])
+    out = ks.rescale(eng.upload(parts), 2).download().reshape(2, L - 1, N)
+    # decrypt over Q' = Q / q_last, CRT to a centred integer, compare with m / q_last
+    Qp = Q[:-1]
+    Qprod = 1
+    for q in Qp:
+        Qprod *= int(q)
+    dec = []
+    for j, q in enumerate(Qp):
+        x0 = O.nwt_inverse(out[0, j], q, rps[j]).astype(object)
+        x1 = O.polymul_ntt(O.nwt_inverse(out[1, j], q, rps[j]), res(s, q), psi[j], q).astype(object)
+        dec.append((x0 + x1) % q)
+    bound = 1 + sum(abs(v) for v in s)
+    for i in range(0, N, 7):
+        x = 0
+        for j, q in enumerate(Qp):
+            Mj = Qprod // int(q)
+            x += int(dec[j][i]) * Mj * pow(Mj, -1, int(q))
+        x %= Qprod
+        x = x - Qprod if x > Qprod // 2 else x
+        err = x * int(ql) - big_m[i]                         # = -(delta0 + delta1 s)_i up to the wrap of c0 + c1 s modulo Q
+        # c0 + c1 s = m + k Q for a small integer polynomial k (|k| <= 1 + |s|_1): remove the multiple of Q that rides along
+        Qfull = Qprod * int(ql)
+        err -= round(err / Qfull) * Qfull
+        assert abs(err) <= bound * int(ql), (i, err)
+    eng.check()
+
+
+def test_fourstep_range_is_pinned(F, eng):
+    """n1 * n2 <= 2^20 and mod < 2^61 (include/fhe_mi355x.h): the sizes beyond return a status, not a wrong answer."""
+    import ctypes as C
+    from fhe_reliability_gpu_amd._lib import lib
+    h = C.c_void_p()
+    assert lib.fhe_fourstep_create(eng._h, 1 << 11, 1 << 10, 998244353, 3, C.byref(h)) != 0          # N = 2^21 (divides mod - 1: 2^23)
+    assert b"2^20" in lib.fhe_last_error()
+    assert lib.fhe_fourstep_create(eng._h, 1 << 10, 1 << 10, 998244353, 3, C.byref(h)) == 0          # N = 2^20: the largest plan
+    lib.fhe_fourstep_destroy(h)
