@@ -466,10 +466,22 @@ __device__ __forceinline__ void bc_exact_fixed(const BcJob &job, u64 N, u32 oc)
             for (int e = 0; e < CPT; e++) c[j][e] = B::digit(t[e], cx);
             bc_sched_fence();
         }
+        // FP64 limbs: the digits' halves for the split products of the output loop
+        double c1[M][CPT], c0[M][CPT];
+        if constexpr (std::is_same<B, BcF64>::value) {
+#pragma unroll
+            for (int l = 0; l < M; l++)
+#pragma unroll
+                for (int e = 0; e < CPT; e++) {
+                    c1[l][e] = __builtin_rint(c[l][e] * 0x1p-25);
+                    c0[l][e] = __builtin_fma(c1[l][e], -0x1p25, c[l][e]);
+                }
+        }
 #pragma unroll 1
         for (int ob = 0; ob < cnt; ob += OU) {
             bc_no_hoist();
             T acc[OU][CPT];
+            double S2[OU][CPT], S1[OU][CPT], S0[OU][CPT];          // (FP64 limbs)
             int oo[OU];
 #pragma unroll
             for (int u = 0; u < OU; u++) oo[u] = ob + u < cnt ? ob + u : cnt - 1;     // the block's tail recomputes the last output (no branch)
@@ -487,40 +499,36 @@ __device__ __forceinline__ void bc_exact_fixed(const BcJob &job, u64 N, u32 oc)
                     for (int u = 0; u < OU; u++) w[(l + 1) & 1][u] = s_rec[oo[u] * REC + l + 1];      // next limb's constants: in flight under this limb's products
                 }
                 if constexpr (std::is_same<B, BcF64>::value) {
-                    // the OU products of this limb step by step, side by side: a product is a chain of five dependent FP64 instructions, and
-                    // written one product after the other a wave has nothing else to issue while each link completes
-                    double h[OU][CPT], kq[OU][CPT], lo[OU][CPT];
+                    // FP64 limbs: digit and constant are split into halves of 25 bits, c = c1 2^25 + c0, E = e1 2^25 + e0 (c0, e0 centred), so that
+                    // every partial product is an exact integer below 2^50 and a term costs FOUR fused multiply-adds into three exact sums
+                    //   S2 += c1 e1,  S1 += c1 e0 + c0 e1,  S0 += c0 e0      (x mod q = S2 2^50 + S1 2^25 + S0 mod q, formed once per output)
+                    // instead of the seven instructions of a modular product and its accumulation.  Eight terms of at most 2^50 stay
+                    // exact below 2^53; longer bases fold S2 and S1 modulo q before the ninth and the sixteenth term.
+                    if (l == 8 || l == 15) {
+#pragma unroll
+                        for (int u = 0; u < OU; u++)
+#pragma unroll
+                            for (int e = 0; e < CPT; e++) {
+                                ArithF64::reduce(S2[u][e], cxu[u]);
+                                ArithF64::reduce(S1[u][e], cxu[u]);
+                            }
+                    }
 #pragma unroll
                     for (int u = 0; u < OU; u++)
 #pragma unroll
-                        for (int e = 0; e < CPT; e++) h[u][e] = c[l][e] * u64_bits_to_double(w[l & 1][u].a);
+                        for (int e = 0; e < CPT; e++) S2[u][e] = l == 0 ? c1[l][e] * u64_bits_to_double(w[l & 1][u].a) : __builtin_fma(c1[l][e], u64_bits_to_double(w[l & 1][u].a), S2[u][e]);
 #pragma unroll
                     for (int u = 0; u < OU; u++)
 #pragma unroll
-                        for (int e = 0; e < CPT; e++) kq[u][e] = c[l][e] * u64_bits_to_double(w[l & 1][u].b);
+                        for (int e = 0; e < CPT; e++) S1[u][e] = l == 0 ? c1[l][e] * u64_bits_to_double(w[l & 1][u].b) : __builtin_fma(c1[l][e], u64_bits_to_double(w[l & 1][u].b), S1[u][e]);
 #pragma unroll
                     for (int u = 0; u < OU; u++)
 #pragma unroll
-                        for (int e = 0; e < CPT; e++) kq[u][e] = __builtin_rint(kq[u][e]);
+                        for (int e = 0; e < CPT; e++) S0[u][e] = l == 0 ? c0[l][e] * u64_bits_to_double(w[l & 1][u].b) : __builtin_fma(c0[l][e], u64_bits_to_double(w[l & 1][u].b), S0[u][e]);
 #pragma unroll
                     for (int u = 0; u < OU; u++)
 #pragma unroll
-                        for (int e = 0; e < CPT; e++) lo[u][e] = __builtin_fma(c[l][e], u64_bits_to_double(w[l & 1][u].a), -h[u][e]);
-#pragma unroll
-                    for (int u = 0; u < OU; u++)
-#pragma unroll
-                        for (int e = 0; e < CPT; e++) h[u][e] = __builtin_fma(-kq[u][e], cxu[u].n, h[u][e]);
-#pragma unroll
-                    for (int u = 0; u < OU; u++)
-#pragma unroll
-                        for (int e = 0; e < CPT; e++) h[u][e] += lo[u][e];
-#pragma unroll
-                    for (int u = 0; u < OU; u++)
-#pragma unroll
-                        for (int e = 0; e < CPT; e++) {
-                            acc[u][e] = l == 0 ? h[u][e] : acc[u][e] + h[u][e];
-                            if (l) B::relax(acc[u][e], l, cxu[u]);
-                        }
+                        for (int e = 0; e < CPT; e++) S1[u][e] = __builtin_fma(c0[l][e], u64_bits_to_double(w[l & 1][u].a), S1[u][e]);
                 } else {
 #pragma unroll
                     for (int u = 0; u < OU; u++) {
@@ -542,6 +550,17 @@ __device__ __forceinline__ void bc_exact_fixed(const BcJob &job, u64 N, u32 oc)
             for (int u = 0; u < OU; u++) {
                 const int o = o0 + oo[u];
                 u64 FHE_GLOBAL *dst = out + (u64)((u32)o < job.gap_at ? o : o + job.gap) * N + i;
+                if constexpr (std::is_same<B, BcF64>::value) {
+                    // S2 2^50 + S1 2^25 + S0 mod q: the two scaled sums are exact doubles (powers of two), each reduced by one quotient estimate
+#pragma unroll
+                    for (int e = 0; e < CPT; e++) {
+                        const double A = S2[u][e] * 0x1p50, Bv = S1[u][e] * 0x1p25;
+                        const double ka = __builtin_rint(A * cxu[u].ninv), kb = __builtin_rint(Bv * cxu[u].ninv);
+                        double r = __builtin_fma(-ka, cxu[u].n, A) + __builtin_fma(-kb, cxu[u].n, Bv);
+                        ArithF64::reduce(r, cxu[u]);
+                        acc[u][e] = r + S0[u][e];
+                    }
+                }
                 if constexpr (CPT == 2) *reinterpret_cast<u64x2 FHE_GLOBAL *>(dst) = u64x2{B::out(acc[u][0], cxu[u]), B::out(acc[u][1], cxu[u])};
                 else *dst = B::out(acc[u][0], cxu[u]);
             }
@@ -638,7 +657,8 @@ static void launch_fixed(hipStream_t st, const BcJob *dev_jobs, const BcJob &job
         const u32 gx = (u32)(want > 16384 ? 16384 : want);
         const u32 slices = bc_slices(gx, n_jobs, m, max_k, (u32)target), oc = ((u32)max_k + slices - 1) / slices;
         const dim3 grid(gx, ((u32)max_k + oc - 1) / oc, n_jobs);
-        const bool wide = std::is_same<B, BcF64>::value ? m <= 14 : m <= 11;
+        static const int ou_env = bc_env("FHE_BC_OU", 0);
+        const bool wide = ou_env ? ou_env == 4 : std::is_same<B, BcF64>::value ? m <= 11 : m <= 11;
         if (wide) launch_fixed_m<B, 1, 4>(st, grid, dev_jobs, job, m, N, oc);
         else launch_fixed_m<B, 1, 2>(st, grid, dev_jobs, job, m, N, oc);
     }

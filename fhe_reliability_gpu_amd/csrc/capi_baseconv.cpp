@@ -81,7 +81,18 @@ int fhe_baseconv_create(fhe_ctx *ctx, const uint64_t *mod_in, int m, const uint6
             (j & 1 ? e.b : e.a) = mi[j];
         }
         for (int o = 0; o < k; o++) {
-            for (int l = 0; l < m; l++) outs[(size_t)o * (m + 2) + l] = hor[(size_t)l * k + o];
+            // FP64 plans: the output constants as two halves of 25 bits, E = e1 2^25 + e0 with e0 centred (the fixed-size kernels'
+            // split products); integer plans: the Shoup pairs
+            u64 prod = 1 % mo[o];
+            for (int l = 0; l < m; l++) {
+                if (f64) {
+                    const double E = (double)prod, e1 = __builtin_rint(E * 0x1p-25), e0 = E - e1 * 0x1p25;
+                    outs[(size_t)o * (m + 2) + l] = Tw{double_to_u64_bits(e1), double_to_u64_bits(e0)};
+                } else {
+                    outs[(size_t)o * (m + 2) + l] = hor[(size_t)l * k + o];
+                }
+                prod = host::mul_mod(prod, mi[l] % mo[o], mo[o]);
+            }
             outs[(size_t)o * (m + 2) + m] = fpo[o];
             outs[(size_t)o * (m + 2) + m + 1] = Tw{mo[o], 0};
         }
