@@ -398,8 +398,155 @@ def main():
     eng.set_option("ntt_chunk_mib", 96)
     eng.set_option("ntt_split", -1)
 
+    # (the sharded legs run BEFORE the single-GPU legs below: measured after them -- after their gigabytes of allocations and frees -- the
+    # same one-rank rotation read 740 us instead of 375, while the identical calls in a fresh process read 348: an artefact of this
+    # process's allocation history, not of the path)
+    # ------------------------------------------------------------------ strong scaling: config 5 with the limbs sharded
+    if extras:
+        def strong_scaling(kind):
+            # BASELINE configs[4] (kind "rotate": one rotation at N = 2^16, L = 44, K = 11, dnum = 4) and configs[3] (kind "hmult":
+            # multiply + relinearize + rescale at N = 2^17, L = 32, K = 8, dnum = 4) with the limbs sharded over the ranks: the
+            # fhe_keyswitch_shard_* / fhe_rescale_shard_* phases on each GPU, two in-place RCCL all-gathers per key switch and one
+            # broadcast per rescale (dist.sharded_rotate / sharded_hmult).  Total work is fixed as the rank count grows; per call:
+            # the compute phases and the joins from CUDA events on this rank's stream, max over ranks.
+            from fhe_reliability_gpu_amd.dist import ShardedKeySwitch, ks_layout, sharded_hmult, sharded_rotate
+            logn, L, K, dnum, reps = (16, 44, 11, 4, 60) if kind == "rotate" else (17, 32, 8, 4, 40)
+            n = 1 << logn
+            qk = F.create_moduli(n, [args.bits] * (L + K))
+            tk = eng.tables(logn, qk)
+            lay = ks_layout(L, K, world, rank)
+            # every rank draws the SAME full operands (one seed) and keeps its own rows: rank 0 can then run the single-device
+            # composite on the full operands and compare it with the gathered result of the sharded run
+            gg = torch.Generator(device="cuda")
+            gg.manual_seed(7)
+            mk = lambda *shape: torch.randint(0, qk[0], shape, generator=gg, device="cuda", dtype=torch.int64)
+            full = [mk(L, n) for _ in range(4)]
+            gk_full = mk(dnum, 2, L + K, n)
+            ct_rows = slice(lay["clo"], lay["clo"] + lay["cn"])
+            key_rows = list(range(lay["clo"], lay["clo"] + lay["cn"])) + list(range(lay["slo"], lay["slo"] + lay["sn"]))
+            c0, c1, b0, b1 = (x[ct_rows].contiguous() for x in full)
+            gk = gk_full[:, :, key_rows, :].contiguous()
+            if not (world > 1 and rank == 0):
+                del full, gk_full
+            # every rank finishes its own set-up before the first collective: a rank that failed here must not leave the others
+            # waiting inside an all-gather
+            err = None
+            try:
+                plan = ShardedKeySwitch(eng, tk, L, K, dnum)
+            except Exception as ex:
+                err = ex
+            if world > 1:
+                bad = torch.tensor([1 if err else 0], device="cuda", dtype=torch.int32)
+                dist.all_reduce(bad, op=dist.ReduceOp.MAX)
+                if int(bad.item()) and err is None:
+                    err = RuntimeError("another rank could not build its sharded plan")
+            if err:
+                raise err
+            if kind == "rotate":
+                call = lambda tm=None: sharded_rotate(plan, c0, c1, 3, gk, timings=tm)
+            else:
+                call = lambda tm=None: sharded_hmult(plan, c0, c1, b0, b1, gk, rescale=True, timings=tm)
+            equal = None
+            with torch.cuda.stream(stream):
+                if world > 1:
+                    # untimed self-check of the first real multi-rank run: gather every rank's rows of the result on all ranks
+                    # (padded slabs, one in-place all-gather per part) and compare on rank 0 with fhe_rotate / fhe_hmult on one device
+                    from fhe_reliability_gpu_amd.dist import all_gather_slots
+                    outs = call()
+                    rows_max = lay["cmax"]
+                    got = []
+                    for part in outs:
+                        buf = torch.zeros((world * rows_max, n), dtype=torch.int64, device="cuda")
+                        buf[rank * rows_max:rank * rows_max + part.shape[0]] = part
+                        all_gather_slots(buf, rows_max)
+                        got.append(buf)
+                    torch.cuda.synchronize()
+                    if rank == 0:
+                        ks1 = F.KeySwitch(eng, tk, L, K, dnum)
+                        lo = L - 1 if kind == "hmult" else L
+                        w0, w1 = torch.empty((lo, n), dtype=torch.int64, device="cuda"), torch.empty((lo, n), dtype=torch.int64, device="cuda")
+                        if kind == "rotate":
+                            check(lib.fhe_rotate(eng._h, ks1._h, P(w0), P(w1), P(full[0]), P(full[1]), 3, P(gk_full), sptr))
+                        else:
+                            check(lib.fhe_hmult(eng._h, ks1._h, P(w0), P(w1), P(full[0]), P(full[1]), P(full[2]), P(full[3]), P(gk_full), 1, sptr))
+                        torch.cuda.synchronize()
+                        equal = True
+                        for r in range(world):
+                            lr = ks_layout(L, K, world, r)
+                            rows = [l for l in range(lr["clo"], lr["clo"] + lr["cn"]) if l < lo]
+                            for want, have in ((w0, got[0]), (w1, got[1])):
+                                if rows and not torch.equal(have[r * rows_max:r * rows_max + len(rows)], want[rows[0]:rows[0] + len(rows)]):
+                                    equal = False
+                        del ks1, w0, w1, full, gk_full
+                    del got
+                for _ in range(30):      # (a fixed count: every rank must issue the same collectives; enough to bring the clocks back up)
+                    call()
+                barrier()
+                tm = {}
+                e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                tw = time.perf_counter()
+                e0.record()
+                for _ in range(reps):
+                    call(tm)
+                e1.record()
+                barrier()
+                wall_c = (time.perf_counter() - tw) / reps
+            evs = tm["events"]
+            seg = [sum(e[i].elapsed_time(e[i + 1]) for e in evs) / len(evs) for i in range(5)]
+            bc = 0.0
+            if "rescale_events" in tm:
+                bc = sum(e[1].elapsed_time(e[2]) for e in tm["rescale_events"]) / len(tm["rescale_events"])
+            tot = e0.elapsed_time(e1) / reps
+            vals = torch.tensor([tot - seg[1] - seg[3] - bc, seg[1], seg[3], bc, tot, wall_c * 1e3], device="cuda", dtype=torch.float64)
+            if world > 1:
+                dist.all_reduce(vals, op=dist.ReduceOp.MAX)
+            comp, j1, j2, jb, tot, wl = (float(x) for x in vals.tolist())
+            ntt_count = L + dnum * (L + K) - L + 2 * K + 2 * L + (2 + 2 * (L - 1) if kind == "hmult" else 0)
+            name = "strong_scaling_config5" if kind == "rotate" else "strong_scaling_config4"
+            what = "one rotation" if kind == "rotate" else "one hmult (multiply + relinearize + rescale)"
+            out = {
+                "workload": f"{what}, N=2^{logn}, L={L}, K={K}, dnum={dnum}, limbs sharded over {world} rank(s) "
+                            f"(rank 0 owns {lay['cn']} ciphertext + {lay['sn']} special limbs)",
+                "scaling": "strong", "n_gpus": world, "backend": (dist.get_backend() if world > 1 else "none (1 rank: no collective issued)"),
+                "us_per_call_device": tot * 1e3, "us_per_call_wall": wl * 1e3,
+                "us_compute_phases": comp * 1e3, "us_all_gather_1 (input, coefficient form)": j1 * 1e3,
+                "us_all_gather_2 (special limbs of both halves)": j2 * 1e3,
+                "bytes_all_gather_1_per_rank": plan.rows1 * n * 8, "bytes_all_gather_2_per_rank": plan.rows2 * n * 8,
+                "limb_ntts_per_call": ntt_count, "limb_ntt_per_s": ntt_count / (tot * 1e-3)}
+            if kind == "hmult":
+                out["us_broadcast (last limbs of both parts)"] = jb * 1e3
+                out["bytes_broadcast"] = 2 * n * 8
+            if world > 1:
+                out["sharded_equals_single"] = equal       # rank 0: gathered rows == fhe_rotate / fhe_hmult on one device, word for word
+            out["traffic_floor_us"] = traffic_floor_us(kind, logn, L, K, dnum)
+            del plan
+            return {name: out}
+        # A collective that never completes (a rank lost, a fabric fault) must not cost the headline: past the limit every rank
+        # leaves, rank 0 with the JSON line it has (the leg marked as timed out) -- the one line the contract asks for either way.
+        import threading
+        done = threading.Event()
+
+        def watchdog():
+            if done.wait(float(os.environ.get("FHE_BENCH_STRONG_LIMIT_S", "240"))):
+                return
+            if rank == 0:
+                also.setdefault("strong_scaling", {"error": "timed out: a sharded leg did not finish within the limit; the headline above is unaffected"})
+                result["also"] = also
+                print(json.dumps(result), flush=True)
+            os._exit(4)      # the line is out; the status says that a leg hung (a collective that never completed must not read as success)
+        if world > 1:
+            threading.Thread(target=watchdog, daemon=True).start()
+        for kind in ("rotate", "hmult"):
+            try:
+                ss = strong_scaling(kind)
+                if rank == 0:
+                    also.update(ss)
+            except Exception as ex:       # the headline must survive a failure of this leg; it is reported, not hidden
+                if rank == 0:
+                    also["strong_scaling_" + kind] = {"error": repr(ex)}
+        done.set()
     # ------------------------------------------------------------------ secondary measurements (rank 0, one GPU)
-    if rank == 0 and extras and world == 1:
+    if rank == 0 and extras and world == 1 and not os.environ.get("FHE_BENCH_SKIP_SINGLE_GPU_LEGS"):
         def rate(limbs, polys, bits, inverse=False, steps=300):
             q2 = F.create_moduli(N, [bits] * limbs)
             t2 = eng.tables(LOGN, q2)
@@ -640,150 +787,6 @@ def main():
                 "ms_per_step_wall": dt * 1e3, "ntt_per_s": cnt * args.limbs / dt, "GBps_each_way": cnt * args.limbs * N * 8 / (dt / 2) / 1e9}}
         also.update(pcie_inclusive())
 
-    # ------------------------------------------------------------------ strong scaling: config 5 with the limbs sharded
-    if extras:
-        def strong_scaling(kind):
-            # BASELINE configs[4] (kind "rotate": one rotation at N = 2^16, L = 44, K = 11, dnum = 4) and configs[3] (kind "hmult":
-            # multiply + relinearize + rescale at N = 2^17, L = 32, K = 8, dnum = 4) with the limbs sharded over the ranks: the
-            # fhe_keyswitch_shard_* / fhe_rescale_shard_* phases on each GPU, two in-place RCCL all-gathers per key switch and one
-            # broadcast per rescale (dist.sharded_rotate / sharded_hmult).  Total work is fixed as the rank count grows; per call:
-            # the compute phases and the joins from CUDA events on this rank's stream, max over ranks.
-            from fhe_reliability_gpu_amd.dist import ShardedKeySwitch, ks_layout, sharded_hmult, sharded_rotate
-            logn, L, K, dnum, reps = (16, 44, 11, 4, 60) if kind == "rotate" else (17, 32, 8, 4, 40)
-            n = 1 << logn
-            qk = F.create_moduli(n, [args.bits] * (L + K))
-            tk = eng.tables(logn, qk)
-            lay = ks_layout(L, K, world, rank)
-            # every rank draws the SAME full operands (one seed) and keeps its own rows: rank 0 can then run the single-device
-            # composite on the full operands and compare it with the gathered result of the sharded run
-            gg = torch.Generator(device="cuda")
-            gg.manual_seed(7)
-            mk = lambda *shape: torch.randint(0, qk[0], shape, generator=gg, device="cuda", dtype=torch.int64)
-            full = [mk(L, n) for _ in range(4)]
-            gk_full = mk(dnum, 2, L + K, n)
-            ct_rows = slice(lay["clo"], lay["clo"] + lay["cn"])
-            key_rows = list(range(lay["clo"], lay["clo"] + lay["cn"])) + list(range(lay["slo"], lay["slo"] + lay["sn"]))
-            c0, c1, b0, b1 = (x[ct_rows].contiguous() for x in full)
-            gk = gk_full[:, :, key_rows, :].contiguous()
-            if not (world > 1 and rank == 0):
-                del full, gk_full
-            # every rank finishes its own set-up before the first collective: a rank that failed here must not leave the others
-            # waiting inside an all-gather
-            err = None
-            try:
-                plan = ShardedKeySwitch(eng, tk, L, K, dnum)
-            except Exception as ex:
-                err = ex
-            if world > 1:
-                bad = torch.tensor([1 if err else 0], device="cuda", dtype=torch.int32)
-                dist.all_reduce(bad, op=dist.ReduceOp.MAX)
-                if int(bad.item()) and err is None:
-                    err = RuntimeError("another rank could not build its sharded plan")
-            if err:
-                raise err
-            if kind == "rotate":
-                call = lambda tm=None: sharded_rotate(plan, c0, c1, 3, gk, timings=tm)
-            else:
-                call = lambda tm=None: sharded_hmult(plan, c0, c1, b0, b1, gk, rescale=True, timings=tm)
-            equal = None
-            with torch.cuda.stream(stream):
-                if world > 1:
-                    # untimed self-check of the first real multi-rank run: gather every rank's rows of the result on all ranks
-                    # (padded slabs, one in-place all-gather per part) and compare on rank 0 with fhe_rotate / fhe_hmult on one device
-                    from fhe_reliability_gpu_amd.dist import all_gather_slots
-                    outs = call()
-                    rows_max = lay["cmax"]
-                    got = []
-                    for part in outs:
-                        buf = torch.zeros((world * rows_max, n), dtype=torch.int64, device="cuda")
-                        buf[rank * rows_max:rank * rows_max + part.shape[0]] = part
-                        all_gather_slots(buf, rows_max)
-                        got.append(buf)
-                    torch.cuda.synchronize()
-                    if rank == 0:
-                        ks1 = F.KeySwitch(eng, tk, L, K, dnum)
-                        lo = L - 1 if kind == "hmult" else L
-                        w0, w1 = torch.empty((lo, n), dtype=torch.int64, device="cuda"), torch.empty((lo, n), dtype=torch.int64, device="cuda")
-                        if kind == "rotate":
-                            check(lib.fhe_rotate(eng._h, ks1._h, P(w0), P(w1), P(full[0]), P(full[1]), 3, P(gk_full), sptr))
-                        else:
-                            check(lib.fhe_hmult(eng._h, ks1._h, P(w0), P(w1), P(full[0]), P(full[1]), P(full[2]), P(full[3]), P(gk_full), 1, sptr))
-                        torch.cuda.synchronize()
-                        equal = True
-                        for r in range(world):
-                            lr = ks_layout(L, K, world, r)
-                            rows = [l for l in range(lr["clo"], lr["clo"] + lr["cn"]) if l < lo]
-                            for want, have in ((w0, got[0]), (w1, got[1])):
-                                if rows and not torch.equal(have[r * rows_max:r * rows_max + len(rows)], want[rows[0]:rows[0] + len(rows)]):
-                                    equal = False
-                        del ks1, w0, w1, full, gk_full
-                    del got
-                for _ in range(30):      # (a fixed count: every rank must issue the same collectives; enough to bring the clocks back up)
-                    call()
-                barrier()
-                tm = {}
-                e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-                tw = time.perf_counter()
-                e0.record()
-                for _ in range(reps):
-                    call(tm)
-                e1.record()
-                barrier()
-                wall_c = (time.perf_counter() - tw) / reps
-            evs = tm["events"]
-            seg = [sum(e[i].elapsed_time(e[i + 1]) for e in evs) / len(evs) for i in range(5)]
-            bc = 0.0
-            if "rescale_events" in tm:
-                bc = sum(e[1].elapsed_time(e[2]) for e in tm["rescale_events"]) / len(tm["rescale_events"])
-            tot = e0.elapsed_time(e1) / reps
-            vals = torch.tensor([tot - seg[1] - seg[3] - bc, seg[1], seg[3], bc, tot, wall_c * 1e3], device="cuda", dtype=torch.float64)
-            if world > 1:
-                dist.all_reduce(vals, op=dist.ReduceOp.MAX)
-            comp, j1, j2, jb, tot, wl = (float(x) for x in vals.tolist())
-            ntt_count = L + dnum * (L + K) - L + 2 * K + 2 * L + (2 + 2 * (L - 1) if kind == "hmult" else 0)
-            name = "strong_scaling_config5" if kind == "rotate" else "strong_scaling_config4"
-            what = "one rotation" if kind == "rotate" else "one hmult (multiply + relinearize + rescale)"
-            out = {
-                "workload": f"{what}, N=2^{logn}, L={L}, K={K}, dnum={dnum}, limbs sharded over {world} rank(s) "
-                            f"(rank 0 owns {lay['cn']} ciphertext + {lay['sn']} special limbs)",
-                "scaling": "strong", "n_gpus": world, "backend": (dist.get_backend() if world > 1 else "none (1 rank: no collective issued)"),
-                "us_per_call_device": tot * 1e3, "us_per_call_wall": wl * 1e3,
-                "us_compute_phases": comp * 1e3, "us_all_gather_1 (input, coefficient form)": j1 * 1e3,
-                "us_all_gather_2 (special limbs of both halves)": j2 * 1e3,
-                "bytes_all_gather_1_per_rank": plan.rows1 * n * 8, "bytes_all_gather_2_per_rank": plan.rows2 * n * 8,
-                "limb_ntts_per_call": ntt_count, "limb_ntt_per_s": ntt_count / (tot * 1e-3)}
-            if kind == "hmult":
-                out["us_broadcast (last limbs of both parts)"] = jb * 1e3
-                out["bytes_broadcast"] = 2 * n * 8
-            if world > 1:
-                out["sharded_equals_single"] = equal       # rank 0: gathered rows == fhe_rotate / fhe_hmult on one device, word for word
-            out["traffic_floor_us"] = traffic_floor_us(kind, logn, L, K, dnum)
-            del plan
-            return {name: out}
-        # A collective that never completes (a rank lost, a fabric fault) must not cost the headline: past the limit every rank
-        # leaves, rank 0 with the JSON line it has (the leg marked as timed out) -- the one line the contract asks for either way.
-        import threading
-        done = threading.Event()
-
-        def watchdog():
-            if done.wait(float(os.environ.get("FHE_BENCH_STRONG_LIMIT_S", "240"))):
-                return
-            if rank == 0:
-                also.setdefault("strong_scaling", {"error": "timed out: a sharded leg did not finish within the limit; the headline above is unaffected"})
-                result["also"] = also
-                print(json.dumps(result), flush=True)
-            os._exit(4)      # the line is out; the status says that a leg hung (a collective that never completed must not read as success)
-        if world > 1:
-            threading.Thread(target=watchdog, daemon=True).start()
-        for kind in ("rotate", "hmult"):
-            try:
-                ss = strong_scaling(kind)
-                if rank == 0:
-                    also.update(ss)
-            except Exception as ex:       # the headline must survive a failure of this leg; it is reported, not hidden
-                if rank == 0:
-                    also["strong_scaling_" + kind] = {"error": repr(ex)}
-        done.set()
     if rank == 0 and also:
         result["also"] = also
 
