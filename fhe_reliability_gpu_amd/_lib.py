@@ -103,6 +103,10 @@ _SIG = {
     "fhe_rotate": (ci, [vp, vp, vp, vp, vp, vp, C.c_uint32, vp, vp]),
     "fhe_galois_key_prepare": (ci, [vp, vp, vp, vp, C.c_uint32, vp]),
     "fhe_rotate_hoisted": (ci, [vp, vp, C.POINTER(vp), C.POINTER(vp), vp, vp, C.POINTER(C.c_uint32), C.POINTER(vp), sz, vp]),
+    "fhe_rotate_hoisted_shard_begin": (ci, [vp, vp, vp, vp]),
+    "fhe_rotate_hoisted_shard_extend": (ci, [vp, vp, vp]),
+    "fhe_rotate_hoisted_shard_inner": (ci, [vp, vp, vp, vp, C.c_uint32, vp]),
+    "fhe_rotate_hoisted_shard_finish": (ci, [vp, vp, vp, vp, vp, C.c_uint32, vp]),
     "fhe_bsgs_matvec": (ci, [vp, vp, vp, vp, vp, vp, vp, sz, sz, C.POINTER(C.c_uint32), C.POINTER(vp), C.POINTER(C.c_uint32), C.POINTER(vp), vp]),
     "fhe_rotate_shard_begin": (ci, [vp, vp, vp, C.c_uint32, vp]),
     "fhe_rotate_shard_inner": (ci, [vp, vp, vp, vp]),

@@ -287,7 +287,8 @@ static int ks_extend_mac(fhe_ctx *ctx, fhe_keyswitch *p, const uint64_t *d_c, co
 
 // opening of the mod-down (MODSWITCH, 16384_4:454-463): the owned special limbs of both halves to coefficient form -- in
 // place inside acc ([2][MO][N]) on one device, in this rank's slot of gather buffer 2 ([2][smax][N]) when sharded
-static int ks_special_intt(fhe_ctx *ctx, fhe_keyswitch *p, hipStream_t st)
+// galois != 0 (a hoisted rotation on a sharded plan): the sums are still in the un-rotated frame, sigma is taken on this INTT's load
+static int ks_special_intt(fhe_ctx *ctx, fhe_keyswitch *p, hipStream_t st, u32 galois = 0)
 {
     const fhe_ntt_tables *t = p->t;
     const KsShard &sh = p->sh;
@@ -297,6 +298,7 @@ static int ks_special_intt(fhe_ctx *ctx, fhe_keyswitch *p, hipStream_t st)
     u64 *acc = p->acc.as<u64>(), *sp = acc + (size_t)sh.cn * N;
     u32 stride = (u32)MO;
     int rc;
+    if (galois && (!p->sharded || p->log_n < 5)) return fail(FHE_ERR_UNSUPPORTED, "the Galois map on the special limbs' INTT needs the out-of-place (sharded) form and N >= 2^5");
     // sharded: out of place, from acc straight into this rank's slot of gather buffer 2 (round 2 copied the rows there first)
     const u64 *from = nullptr;
     if (p->sharded) {
@@ -311,6 +313,7 @@ static int ks_special_intt(fhe_ctx *ctx, fhe_keyswitch *p, hipStream_t st)
             if (from) {
                 a.src = from + off * N;
                 a.src_stride = (u32)MO;
+                a.galois = galois;
             }
             hipError_t e2 = launch_ntt(st, a, p->log_n, true, path, 1);
             return e2 == hipSuccess ? FHE_OK : hip_fail(e2, "launch_ntt");
@@ -338,8 +341,9 @@ static bool ks_fast_path(const fhe_ctx *ctx, const fhe_keyswitch *p)
 // sp_hoist != nullptr (a hoisted rotation): the special limbs in coefficient form sit there ([2][K][N]) and the sums in acc are still in
 // the un-rotated frame -- the tail reads them through the Galois map as well
 static int ks_finish(fhe_ctx *ctx, fhe_keyswitch *p, uint64_t *d_out0, uint64_t *d_out1, const uint64_t *d_add0, const uint64_t *d_add1,
-                     hipStream_t st, u32 galois = 0, const u64 *sp_hoist = nullptr)
+                     hipStream_t st, u32 galois = 0, const u64 *sp_hoist = nullptr, bool galois_acc = false)
 {
+    galois_acc = galois_acc || sp_hoist != nullptr;
     const fhe_ntt_tables *t = p->t;
     const KsShard &sh = p->sh;
     if (!sh.cn) return FHE_OK;
@@ -352,7 +356,7 @@ static int ks_finish(fhe_ctx *ctx, fhe_keyswitch *p, uint64_t *d_out0, uint64_t 
     if (plain && galois) return fail(FHE_ERR_INVALID, "the Galois map on the addends belongs to the fused tail");
     // one special prime at a two-launch size: the conversion x mod q_j rides on the converted limbs' column pass
     const bool trivial = p->K == 1 && p->log_n >= 13 && !plain;
-    if (sp_hoist && plain) return fail(FHE_ERR_UNSUPPORTED, "hoisted rotations need the fused mod-down tail");
+    if (galois_acc && plain) return fail(FHE_ERR_UNSUPPORTED, "hoisted rotations need the fused mod-down tail");
     if (!trivial) {
         e = launch_baseconv_exact_jobs(st, (sp_hoist ? p->hdown_jobs : p->down_jobs).as<BcJob>(), 2, p->down->dev.m, p->down->dev.k, p->down->dev.f64 != 0, N, p->down->dev.m <= 16 ? 1u << (p->down->dev.m - 1) : 0u);
         if (e != hipSuccess) return hip_fail(e, "launch_baseconv_exact_jobs");
@@ -372,7 +376,7 @@ static int ks_finish(fhe_ctx *ctx, fhe_keyswitch *p, uint64_t *d_out0, uint64_t 
         RowEpiArgs ep{{d_out0 + off * N, d_out1 + off * N, nullptr}, {d_add0 ? d_add0 + off * N : nullptr, d_add1 ? d_add1 + off * N : nullptr, nullptr},
                       acc + off * N, (u64)(MO * N), p->pinv.as<u64>() + off};
         ep.galois = galois;
-        ep.galois_a = sp_hoist ? 1u : 0u;
+        ep.galois_a = galois_acc ? 1u : 0u;
         if (trivial) {
             a.src = sp_hoist ? sp_hoist : (p->sharded ? p->g2 : acc) + (size_t)p->down_src_row * N;
             a.src_bcast = sp_hoist ? (u64)p->K * N : (u64)p->down_src_stride * N;
@@ -649,6 +653,52 @@ extern "C" int fhe_rotate_hoisted(fhe_ctx *ctx, fhe_keyswitch *p, uint64_t *cons
         if ((rc = ks_finish(ctx, p, d_out0[r], d_out1[r], d_c0, nullptr, st, g, hsp))) return rc;
     }
     return FHE_OK;
+}
+
+// Hoisted rotations on a limb-sharded plan: the input's all-gather (gather 1) and the digit extension are shared by all Galois elements,
+// per element only the inner product, the special limbs' all-gather (gather 2) and the mod-down run -- ONE collective per rotation
+// instead of two.
+//   fhe_rotate_hoisted_shard_begin   INTT of the owned limbs of c1 (un-rotated) into gather buffer 1     -- all-gather 1 (once) --
+//   fhe_rotate_hoisted_shard_extend  extension of every digit to the owned limbs + column pass            (once)
+//   fhe_rotate_hoisted_shard_inner   per element: inner product with the owned rows of the prepared key, INTT of sigma(owned special
+//                                    limbs of the sums) into gather buffer 2                              -- all-gather 2 --
+//   fhe_rotate_hoisted_shard_finish  per element: mod-down to the owned limbs, sums and c0 read through the Galois map
+extern "C" int fhe_rotate_hoisted_shard_begin(fhe_ctx *ctx, fhe_keyswitch *p, const uint64_t *d_c1_local, void *stream)
+{
+    if (!ctx || !p || (!d_c1_local && p->sh.cn)) return fail(FHE_ERR_INVALID, "null argument");
+    if (!p->sharded) return fail(FHE_ERR_INVALID, "a plan without gather buffers runs fhe_rotate_hoisted");
+    HIP_TRY(hipSetDevice(ctx->device));
+    return ks_begin(ctx, p, d_c1_local, pick(ctx, stream));
+}
+
+extern "C" int fhe_rotate_hoisted_shard_extend(fhe_ctx *ctx, fhe_keyswitch *p, void *stream)
+{
+    if (!ctx || !p) return fail(FHE_ERR_INVALID, "null argument");
+    if (!p->sharded) return fail(FHE_ERR_INVALID, "a plan without gather buffers runs fhe_rotate_hoisted");
+    if (p->log_n < 5 || !ks_fast_path(ctx, p)) return fail(FHE_ERR_UNSUPPORTED, "hoisted rotations need N >= 2^5 and the default transform path");
+    HIP_TRY(hipSetDevice(ctx->device));
+    return ks_extend(ctx, p, pick(ctx, stream), ks_use_fused(ctx, p));
+}
+
+extern "C" int fhe_rotate_hoisted_shard_inner(fhe_ctx *ctx, fhe_keyswitch *p, const uint64_t *d_c1_local, const uint64_t *d_prepared_key_local,
+                                              uint32_t galois_elt, void *stream)
+{
+    if (!ctx || !p || (!d_c1_local && p->sh.cn) || !d_prepared_key_local || !(galois_elt & 1)) return fail(FHE_ERR_INVALID, "bad rotation arguments");
+    if (!p->sharded) return fail(FHE_ERR_INVALID, "a plan without gather buffers runs fhe_rotate_hoisted");
+    HIP_TRY(hipSetDevice(ctx->device));
+    hipStream_t st = pick(ctx, stream);
+    int rc = ks_mac(ctx, p, d_c1_local, d_prepared_key_local, st, ks_use_fused(ctx, p));
+    return rc ? rc : ks_special_intt(ctx, p, st, galois_elt);
+}
+
+extern "C" int fhe_rotate_hoisted_shard_finish(fhe_ctx *ctx, fhe_keyswitch *p, uint64_t *d_out0_local, uint64_t *d_out1_local,
+                                               const uint64_t *d_c0_local, uint32_t galois_elt, void *stream)
+{
+    if (!ctx || !p || ((!d_out0_local || !d_out1_local || !d_c0_local) && p->sh.cn) || !(galois_elt & 1)) return fail(FHE_ERR_INVALID, "bad rotation arguments");
+    if (!p->sharded) return fail(FHE_ERR_INVALID, "a plan without gather buffers runs fhe_rotate_hoisted");
+    if (p->sh.cn && (d_out0_local == d_c0_local || d_out1_local == d_c0_local)) return fail(FHE_ERR_INVALID, "rotate is out of place");
+    HIP_TRY(hipSetDevice(ctx->device));
+    return ks_finish(ctx, p, d_out0_local, d_out1_local, d_c0_local, nullptr, pick(ctx, stream), galois_elt, nullptr, true);
 }
 
 // ---------------------------------------------------------------- baby-step / giant-step matrix-vector product

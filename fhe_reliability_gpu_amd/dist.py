@@ -246,6 +246,37 @@ class ShardedKeySwitch:
         check(lib.fhe_rotate_shard_finish(self.eng._h, self._h, self._p(out0), self._p(out1), self._p(c0_local), galois_elt, self._stream()))
         return out0, out1
 
+    # hoisted rotations: one decomposition (and ONE input all-gather) for all Galois elements, one all-gather per element
+    def prepare_galois_key(self, gk_local, galois_elt: int):
+        """This rank's rows of a Galois key in the un-rotated frame (fhe_galois_key_prepare); once per key."""
+        import torch
+
+        from ._lib import check, lib
+        out = torch.empty_like(gk_local)
+        check(lib.fhe_galois_key_prepare(self.eng._h, self._h, self._p(out), self._p(gk_local), galois_elt, self._stream()))
+        return out
+
+    def hoisted_begin(self, c1_local):
+        from ._lib import check, lib
+        check(lib.fhe_rotate_hoisted_shard_begin(self.eng._h, self._h, self._p(c1_local), self._stream()))
+
+    def hoisted_extend(self):
+        from ._lib import check, lib
+        check(lib.fhe_rotate_hoisted_shard_extend(self.eng._h, self._h, self._stream()))
+
+    def hoisted_inner(self, c1_local, pk_local, galois_elt: int):
+        from ._lib import check, lib
+        check(lib.fhe_rotate_hoisted_shard_inner(self.eng._h, self._h, self._p(c1_local), self._p(pk_local), galois_elt, self._stream()))
+
+    def hoisted_finish(self, c0_local, galois_elt: int):
+        import torch
+
+        from ._lib import check, lib
+        cn = self.lay["cn"]
+        out = torch.empty((2, cn, self.t.N), dtype=torch.int64, device=self.g1.device)
+        check(lib.fhe_rotate_hoisted_shard_finish(self.eng._h, self._h, self._p(out[0]), self._p(out[1]), self._p(c0_local), galois_elt, self._stream()))
+        return out[0], out[1]
+
     def tensor(self, a0, a1, b0, b1):
         """(d0, d1, d2) of the owned limbs (phantom::multiply, dotprod_test.cu:113): no exchange."""
         import torch
@@ -332,6 +363,24 @@ def sharded_rotate(plan, c0_local, c1_local, galois_elt: int, gk_local, timings=
     switch's own launches: the key switch of sigma(c1) with sigma(c0) added to the first part, same two joins."""
     with plan.stream_scope():
         return _sharded_keyswitch(plan, c1_local, gk_local, c0_local, None, timings, galois=galois_elt)
+
+
+def sharded_rotate_hoisted(plan, c0_local, c1_local, galois_elts, prepared_keys_local):
+    """Rotations of ONE sharded ciphertext by several Galois elements (the baby steps of profile_framewk/src/matmul_ckks.cpp:45-113):
+    the input's all-gather and the digit extension happen once, each element costs the inner product, ONE all-gather (the special limbs of
+    its sums) and the mod-down.  prepared_keys_local: this rank's key rows in the un-rotated frame (plan.prepare_galois_key).
+    Returns [(out0_local, out1_local), ...]."""
+    import contextlib
+    with (plan.stream_scope() if hasattr(plan, "stream_scope") else contextlib.nullcontext()):
+        plan.hoisted_begin(c1_local)
+        all_gather_slots(plan.g1, plan.rows1, plan.group)
+        plan.hoisted_extend()
+        outs = []
+        for g, pk in zip(galois_elts, prepared_keys_local):
+            plan.hoisted_inner(c1_local, pk, int(g))
+            all_gather_slots(plan.g2, plan.rows2, plan.group)
+            outs.append(plan.hoisted_finish(c0_local, int(g)))
+        return outs
 
 
 def broadcast_rows(buf, src: int, group=None):

@@ -280,6 +280,17 @@ int fhe_rotate(fhe_ctx *ctx, fhe_keyswitch *p, uint64_t *d_out0, uint64_t *d_out
 int fhe_galois_key_prepare(fhe_ctx *ctx, fhe_keyswitch *p, uint64_t *d_key_out, const uint64_t *d_key_in, uint32_t galois_elt, void *stream);
 int fhe_rotate_hoisted(fhe_ctx *ctx, fhe_keyswitch *p, uint64_t *const *d_out0, uint64_t *const *d_out1, const uint64_t *d_c0,
                        const uint64_t *d_c1, const uint32_t *galois_elts, const uint64_t *const *d_prepared_keys, size_t n_rot, void *stream);
+/* Hoisted rotations with the limbs sharded (plans of fhe_keyswitch_create_sharded): gather 1 and the digit extension are shared by all
+ * elements, so a rotation costs ONE all-gather (the special limbs') instead of two.  Per ciphertext: _begin (INTT of the owned limbs of the
+ * un-rotated c1 into d_gather1), all-gather of d_gather1, _extend; per Galois element: _inner (inner product with the owned rows of the
+ * prepared key -- fhe_galois_key_prepare on the rank's rows --, INTT of sigma(owned special limbs) into d_gather2), all-gather of d_gather2,
+ * _finish (mod-down to the owned limbs; sums and c0 read through the Galois map).  Values as fhe_rotate_hoisted. */
+int fhe_rotate_hoisted_shard_begin(fhe_ctx *ctx, fhe_keyswitch *p, const uint64_t *d_c1_local, void *stream);
+int fhe_rotate_hoisted_shard_extend(fhe_ctx *ctx, fhe_keyswitch *p, void *stream);
+int fhe_rotate_hoisted_shard_inner(fhe_ctx *ctx, fhe_keyswitch *p, const uint64_t *d_c1_local, const uint64_t *d_prepared_key_local,
+                                   uint32_t galois_elt, void *stream);
+int fhe_rotate_hoisted_shard_finish(fhe_ctx *ctx, fhe_keyswitch *p, uint64_t *d_out0_local, uint64_t *d_out1_local, const uint64_t *d_c0_local,
+                                    uint32_t galois_elt, void *stream);
 /* Baby-step / giant-step matrix-vector product on a two-part ciphertext x = (c0, c1) (profile_framewk/src/matmul_ckks.cpp:45-113 --
  * rotate, multiply_plain with a diagonal, add -- in the arrangement with n1 + n2 - 2 rotations; plaintext block form:
  * motivation/bsgs.py:39-52):

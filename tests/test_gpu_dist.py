@@ -228,3 +228,52 @@ def test_real_plan_with_ranks_sharing_the_gpu(tmp_path, world, logn, L, K, dnum,
     assert (np.concatenate([g[4] for g in got], axis=0) == p0).all() and (np.concatenate([g[5] for g in got], axis=0) == p1).all()
     for r in range(world):
         assert got[r].shape[1] == ks_layout(L, K, world, r)["cn"]
+
+
+def _gloo_gpu_hoisted_worker(rank, world, port, logn, L, K, dnum, bits, elts, out_dir):
+    import torch
+    import torch.distributed as dist
+
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        import fhe_reliability_gpu_amd as F
+        from fhe_reliability_gpu_amd.dist import ShardedKeySwitch, ks_layout, own_ct_rows, own_rows, sharded_rotate, sharded_rotate_hoisted
+        eng = F.Engine(0)
+        qs, c1, gk, c0 = _case(logn, L, K, dnum, bits)
+        _, _, gk2, _ = _case(logn, L, K, dnum, bits, seed=9)
+        t = eng.tables(logn, qs)
+        lay = ks_layout(L, K, world, rank)
+        plan = ShardedKeySwitch(eng, t, L, K, dnum)
+        c0_l, c1_l = _to_cuda(c0[own_ct_rows(lay)]), _to_cuda(c1[own_ct_rows(lay)])
+        keys = [_to_cuda(k[:, :, own_rows(lay)]) for k in (gk, gk2, gk)]
+        prepared = [plan.prepare_galois_key(k, e) for k, e in zip(keys, elts)]
+        outs = sharded_rotate_hoisted(plan, c0_l, c1_l, elts, prepared)
+        # the plan still serves a plain sharded rotation afterwards (buffers shared between the two forms)
+        p0, p1 = sharded_rotate(plan, c0_l, c1_l, elts[0], keys[0])
+        torch.cuda.synchronize()
+        np.save(os.path.join(out_dir, f"hr{rank}.npy"), np.stack([_from_cuda(x) for o in outs for x in o] + [_from_cuda(p0), _from_cuda(p1)]))
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("world,logn,L,K,dnum,bits", [(1, 13, 5, 2, 3, 50), (2, 12, 6, 2, 3, 50), (3, 13, 7, 3, 2, 61), (2, 14, 4, 1, 4, 50), (3, 10, 2, 4, 1, 50)])
+def test_sharded_hoisted_rotations_real_plan(tmp_path, world, logn, L, K, dnum, bits):
+    """Hoisted rotations with the limbs sharded (fhe_rotate_hoisted_shard_*; ranks share cuda:0, the joins go over gloo): ONE input
+    all-gather for three Galois elements, one special-limb all-gather per element; concatenated rows equal the oracle composite
+    rotate_hoisted_ref, i.e. what fhe_rotate_hoisted gives on one device."""
+    import torch.multiprocessing as mp
+    from oracle.keyswitch_ref import rotate_hoisted_ref, rotate_ref
+    N = 1 << logn
+    elts = [3, 2 * N - 1, 5]
+    mp.spawn(_gloo_gpu_hoisted_worker, args=(world, _free_port(), logn, L, K, dnum, bits, elts, str(tmp_path)), nprocs=world, join=True)
+    qs, c1, gk, c0 = _case(logn, L, K, dnum, bits)
+    _, _, gk2, _ = _case(logn, L, K, dnum, bits, seed=9)
+    got = [np.load(tmp_path / f"hr{r}.npy") for r in range(world)]
+    cat = lambda i: np.concatenate([g[i] for g in got], axis=0)
+    for r, (e, key) in enumerate(zip(elts, (gk, gk2, gk))):
+        w0, w1 = rotate_hoisted_ref(c0, c1, e, key, qs, L, K, dnum, logn)
+        assert (cat(2 * r) == w0).all() and (cat(2 * r + 1) == w1).all(), f"galois element {e}"
+    v0, v1 = rotate_ref(c0, c1, elts[0], gk, qs, L, K, dnum, logn)
+    assert (cat(6) == v0).all() and (cat(7) == v1).all()
