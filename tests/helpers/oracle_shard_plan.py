@@ -100,6 +100,59 @@ class OracleShardPlan:
             outs.append(out)
         return outs[0], outs[1]
 
+    # ---- hoisted rotations (tests of dist.sharded_rotate_hoisted): the same phases as the C ABI's fhe_rotate_hoisted_shard_*
+    def _sigma(self, x, k, tl):
+        from oracle.keyswitch_ref import galois_coeff
+        q = self.qs[tl]
+        return self.O.nwt_forward(galois_coeff(self.O.nwt_inverse(x, q, self.rps[tl]), k, q), q, self.rps[tl])
+
+    def prepare_galois_key(self, gk_local, galois_elt):
+        import torch
+        kinv = pow(int(galois_elt), -1, 2 * self.N)
+        out = torch.zeros_like(gk_local)
+        for d in range(self.dnum):
+            for h in range(2):
+                for jj, tl in enumerate(self.own):
+                    out[d, h, jj] = self._t(self._sigma(self._np(gk_local[d, h, jj]), kinv, tl))
+        return out
+
+    def hoisted_begin(self, c1_local):
+        self.begin(c1_local)
+
+    def hoisted_extend(self):
+        O, lay = self.O, self.lay
+        self.ext = []                                   # [digit][owned row] NTT form; None where the digit's own limb takes c1 itself
+        for d in range(self.dnum):
+            lo, hi = d * self.alpha, min(self.L, (d + 1) * self.alpha)
+            digit = np.stack([self._np(self.g1[self._row1(l)]) for l in range(lo, hi)])
+            row = []
+            for tl in self.own:
+                row.append(None if lo <= tl < hi else O.nwt_forward(O.baseconv_exact(digit, self.qs[lo:hi], [self.qs[tl]])[0], self.qs[tl], self.rps[tl]))
+            self.ext.append(row)
+
+    def hoisted_inner(self, c1_local, pk_local, galois_elt):
+        O, lay, N = self.O, self.lay, self.N
+        acc = np.zeros((2, len(self.own), N), dtype=np.uint64)
+        for d in range(self.dnum):
+            for jj, tl in enumerate(self.own):
+                x = self.ext[d][jj] if self.ext[d][jj] is not None else self._np(c1_local[tl - lay["clo"]])
+                for h in range(2):
+                    acc[h, jj] = O.modmul_acc(acc[h, jj], x, self._np(pk_local[d, h, jj]), self.qs[tl])
+        # sigma of the sums: the un-rotated frame ends here
+        self.acc = np.stack([np.stack([self._sigma(acc[h, jj], galois_elt, tl) for jj, tl in enumerate(self.own)]) for h in range(2)])
+        for h in range(2):
+            for kk in range(lay["sn"]):
+                tl = lay["slo"] + kk
+                self.g2[(self.rank * 2 + h) * self.smax + kk] = self._t(O.nwt_inverse(self.acc[h, lay["cn"] + kk], self.qs[tl], self.rps[tl]))
+
+    def hoisted_finish(self, c0_local, galois_elt):
+        lay = self.lay
+        sig0 = None
+        if lay["cn"]:
+            import torch
+            sig0 = torch.stack([self._t(self._sigma(self._np(c0_local[j]), galois_elt, lay["clo"] + j)) for j in range(lay["cn"])])
+        return self.finish(sig0, None)
+
     # ---- homomorphic multiply on the owned rows (tests of dist.sharded_hmult)
     def tensor(self, a0, a1, b0, b1):
         import torch

@@ -120,6 +120,47 @@ def test_sharded_keyswitch_gloo(tmp_path, world, L, K, dnum):
         assert got[r].shape[1] == ks_layout(L, K, world, r)["cn"]
 
 
+def _hoist_worker(rank, world, port, logn, L, K, dnum, elts, out_dir):
+    import torch
+    import torch.distributed as dist
+
+    from fhe_reliability_gpu_amd.dist import ks_layout, own_ct_rows, own_rows, sharded_rotate_hoisted
+    from helpers.oracle_shard_plan import OracleShardPlan
+
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        qs, c1, gk, c0 = _ks_case(logn, L, K, dnum)
+        lay = ks_layout(L, K, world, rank)
+        to_t = lambda a: torch.from_numpy(np.ascontiguousarray(a).view(np.int64).copy())
+        plan = OracleShardPlan(qs, logn, L, K, dnum)
+        gk_l = to_t(gk[:, :, own_rows(lay)])
+        prepared = [plan.prepare_galois_key(gk_l, e) for e in elts]
+        outs = sharded_rotate_hoisted(plan, to_t(c0[own_ct_rows(lay)]), to_t(c1[own_ct_rows(lay)]), elts, prepared)
+        np.save(os.path.join(out_dir, f"hz{rank}.npy"), np.stack([x.numpy().view(np.uint64) for o in outs for x in o]))
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("world,L,K,dnum", [(2, 4, 2, 2), (3, 5, 2, 3), (3, 2, 4, 1)])
+def test_sharded_rotate_hoisted_gloo(tmp_path, world, L, K, dnum):
+    """dist.sharded_rotate_hoisted's sequencing over gloo with an oracle-backed plan: ONE all-gather of the input for all Galois
+    elements, one all-gather of the special limbs per element; the concatenated rows equal the single-device hoisted rotation
+    (oracle/keyswitch_ref.py rotate_hoisted_ref)."""
+    import torch.multiprocessing as mp
+    from oracle.keyswitch_ref import rotate_hoisted_ref
+
+    logn = 6
+    elts = [3, 2 * (1 << logn) - 1]
+    mp.spawn(_hoist_worker, args=(world, _free_port(), logn, L, K, dnum, elts, str(tmp_path)), nprocs=world, join=True)
+    qs, c1, gk, c0 = _ks_case(logn, L, K, dnum)
+    got = [np.load(tmp_path / f"hz{r}.npy") for r in range(world)]
+    for r, e in enumerate(elts):
+        w0, w1 = rotate_hoisted_ref(c0, c1, e, gk, qs, L, K, dnum, logn)
+        assert (np.concatenate([g[2 * r] for g in got], axis=0) == w0).all() and (np.concatenate([g[2 * r + 1] for g in got], axis=0) == w1).all(), e
+
+
 def _hm_worker(rank, world, port, logn, L, K, dnum, out_dir):
     import torch
     import torch.distributed as dist
