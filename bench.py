@@ -534,8 +534,82 @@ def main():
                 result["also"] = also
                 print(json.dumps(result), flush=True)
             os._exit(4)      # the line is out; the status says that a leg hung (a collective that never completed must not read as success)
+        def strong_scaling_hoisted():
+            # eight HOISTED baby rotations of one sharded ciphertext at the config-5 shape (dist.sharded_rotate_hoisted): the input's
+            # all-gather and the digit extension once, per rotation the inner product, ONE all-gather and the mod-down
+            from fhe_reliability_gpu_amd.dist import ShardedKeySwitch, all_gather_slots, ks_layout, sharded_rotate_hoisted
+            logn, L, K, dnum, n_rot, reps = 16, 44, 11, 4, 8, 12
+            n = 1 << logn
+            qk = F.create_moduli(n, [args.bits] * (L + K))
+            tk = eng.tables(logn, qk)
+            lay = ks_layout(L, K, world, rank)
+            gg = torch.Generator(device="cuda")
+            gg.manual_seed(11)
+            mk = lambda *shape: torch.randint(0, qk[0], shape, generator=gg, device="cuda", dtype=torch.int64)
+            c0_full, c1_full, gk_full = mk(L, n), mk(L, n), mk(dnum, 2, L + K, n)
+            ct_rows = slice(lay["clo"], lay["clo"] + lay["cn"])
+            key_rows = list(range(lay["clo"], lay["clo"] + lay["cn"])) + list(range(lay["slo"], lay["slo"] + lay["sn"]))
+            c0, c1, gk = c0_full[ct_rows].contiguous(), c1_full[ct_rows].contiguous(), gk_full[:, :, key_rows, :].contiguous()
+            elts = [pow(3, b + 1, 2 * n) for b in range(n_rot)]
+            plan = ShardedKeySwitch(eng, tk, L, K, dnum)
+            with torch.cuda.stream(stream):
+                pk = plan.prepare_galois_key(gk, elts[0])          # (one prepared key stands for all eight: timing and self-check only)
+                call = lambda k=n_rot: sharded_rotate_hoisted(plan, c0, c1, elts[:k], [pk] * k)
+                equal = None
+                if world > 1:
+                    (h0, h1), = call(1)
+                    got = []
+                    for part in (h0, h1):
+                        buf = torch.zeros((world * lay["cmax"], n), dtype=torch.int64, device="cuda")
+                        buf[rank * lay["cmax"]:rank * lay["cmax"] + part.shape[0]] = part
+                        all_gather_slots(buf, lay["cmax"])
+                        got.append(buf)
+                    torch.cuda.synchronize()
+                    if rank == 0:
+                        ks1 = F.KeySwitch(eng, tk, L, K, dnum)
+                        pk1 = torch.empty_like(gk_full)
+                        check(lib.fhe_galois_key_prepare(eng._h, ks1._h, P(pk1), P(gk_full), elts[0], sptr))
+                        w0, w1 = torch.empty((L, n), dtype=torch.int64, device="cuda"), torch.empty((L, n), dtype=torch.int64, device="cuda")
+                        a0, a1, kk, ge = (C.c_void_p * 1)(w0.data_ptr()), (C.c_void_p * 1)(w1.data_ptr()), (C.c_void_p * 1)(pk1.data_ptr()), (C.c_uint32 * 1)(elts[0])
+                        check(lib.fhe_rotate_hoisted(eng._h, ks1._h, a0, a1, P(c0_full), P(c1_full), ge, kk, 1, sptr))
+                        torch.cuda.synchronize()
+                        equal = True
+                        for r in range(world):
+                            lr = ks_layout(L, K, world, r)
+                            for want, have in ((w0, got[0]), (w1, got[1])):
+                                if lr["cn"] and not torch.equal(have[r * lay["cmax"]:r * lay["cmax"] + lr["cn"]], want[lr["clo"]:lr["clo"] + lr["cn"]]):
+                                    equal = False
+                        del ks1, pk1
+                for _ in range(4):
+                    call()
+                barrier()
+                e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                e0.record()
+                for _ in range(reps):
+                    call()
+                e1.record()
+                barrier()
+            vals = torch.tensor([e0.elapsed_time(e1) / reps / n_rot], device="cuda", dtype=torch.float64)
+            if world > 1:
+                dist.all_reduce(vals, op=dist.ReduceOp.MAX)
+            out = {"workload": f"{n_rot} hoisted rotations of one ciphertext, N=2^{logn}, L={L}, K={K}, dnum={dnum}, limbs sharded over {world} rank(s): "
+                               f"one all-gather of the input for all of them, one all-gather of the special limbs per rotation",
+                   "scaling": "strong", "n_gpus": world, "us_per_rotation_device": float(vals.item()) * 1e3,
+                   "bytes_all_gather_per_rotation_per_rank": plan.rows2 * n * 8, "bytes_all_gather_shared_per_rank": plan.rows1 * n * 8}
+            if world > 1:
+                out["sharded_equals_single"] = equal
+            del plan
+            return {"strong_scaling_config5_hoisted": out}
+
         if world > 1:
             threading.Thread(target=watchdog, daemon=True).start()
+        try:
+            ss = strong_scaling_hoisted()
+            if rank == 0:
+                also.update(ss)
+        except Exception as ex:
+            if rank == 0:
+                also["strong_scaling_config5_hoisted"] = {"error": repr(ex)}
         for kind in ("rotate", "hmult"):
             try:
                 ss = strong_scaling(kind)
