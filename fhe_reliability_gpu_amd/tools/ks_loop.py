@@ -14,6 +14,8 @@ hmult = len(sys.argv) > 6 and sys.argv[6] == "hmult"
 hoisted = len(sys.argv) > 6 and sys.argv[6] == "hoisted"
 n = 1 << logn
 eng = F.Engine(0)
+if os.environ.get("FHE_KS_FUSED"):
+    eng.set_option("ks_fused", int(os.environ["FHE_KS_FUSED"]))
 qs = F.create_moduli(n, [50] * (L + K))
 t = eng.tables(logn, qs)
 ks = F.KeySwitch(eng, t, L, K, dnum)
