@@ -126,6 +126,28 @@ hipError_t handoff_scratch(fhe_ctx *ctx, hipStream_t st, size_t bytes, u64 **out
     return hipSuccess;
 }
 
+// the side stream the context keeps for work forked off `st` (created on first use); *out = nullptr inside a stream capture
+int side_stream(fhe_ctx *ctx, hipStream_t st, fhe_ctx::Side **out)
+{
+    *out = nullptr;
+    hipStreamCaptureStatus cap = hipStreamCaptureStatusNone;
+    if (hipStreamIsCapturing(st, &cap) != hipSuccess || cap != hipStreamCaptureStatusNone) return FHE_OK;
+    fhe_ctx::Side *sd;
+    {
+        std::lock_guard<std::mutex> lock(ctx->mu);
+        auto &slot = ctx->side[st];
+        if (!slot) slot.reset(new fhe_ctx::Side);
+        sd = slot.get();
+    }
+    if (!sd->s) {
+        HIP_TRY(hipStreamCreateWithFlags(&sd->s, hipStreamNonBlocking));
+        HIP_TRY(hipEventCreateWithFlags(&sd->fork, hipEventDisableTiming));
+        HIP_TRY(hipEventCreateWithFlags(&sd->join, hipEventDisableTiming));
+    }
+    *out = sd;
+    return FHE_OK;
+}
+
 // fn(stream, piece, side scratch) over the pieces of a call; with "ntt_split" they alternate between the caller's stream and the
 // context's side stream for it (fork / join by events; side scratch = side_tmp_bytes of the side stream's own, null on the caller's
 // stream), so that one piece's row pass runs under the next one's column pass.

@@ -185,6 +185,14 @@ struct fhe_keyswitch {
     DevBuf rs_last, rs_delta, rs_jobs; // rs_last backs rs_bc on one device; [3][rs_n][N] residues; job list (3 parts)
     DevBuf hm, hm_pre;                 // [3][L][N] tensor product, [2][L][N] relinearised product before the rescale
     DevBuf bsgs;                       // fhe_bsgs_matvec: baby rotations, inner sum, one rotated inner sum (grown on demand)
+    // second set of per-rotation buffers: hoisted rotations alternate between the caller's stream and a side stream (one rotation's
+    // conversions run under the next one's inner product); `cur` selects the set the host-side helpers address (launch arguments are
+    // taken at launch time, so flipping it between launches is safe under the one-plan-one-caller rule)
+    DevBuf acc2, conv2, hsp2, hdown_jobs2;
+    int cur = 0;
+    u64 *acc_cur() const { return (cur ? acc2 : acc).as<u64>(); }
+    u64 *conv_cur() const { return (cur ? conv2 : conv).as<u64>(); }
+    u64 *hsp_cur() const { return (cur ? hsp2 : hsp).as<u64>(); }
     DevBuf hsp, hdown_rows, hdown_jobs; // hoisted rotations (allocated on first use): [2][K][N] special limbs of sigma(sums) in coefficient form, the mod-down jobs that read them
     u64 t_inv_qlast = 0;               // plain_modulus^-1 mod q_{L-1} (BGV)
     ~fhe_keyswitch()
@@ -319,6 +327,7 @@ struct SubBatchCut {
 };
 SubBatchCut sub_batch_cut(const fhe_ctx *ctx, int log_n, size_t n_poly, size_t len, size_t bufs = 1);
 size_t sub_batch_polys(const fhe_ctx *ctx, int log_n, size_t n_poly, size_t len);
+int side_stream(fhe_ctx *ctx, hipStream_t st, fhe_ctx::Side **out);
 int for_pieces(fhe_ctx *ctx, hipStream_t st, size_t n_pieces, size_t side_tmp_bytes, const std::function<hipError_t(hipStream_t, size_t, fhe::u64 *)> &fn);
 hipError_t handoff_scratch(fhe_ctx *ctx, hipStream_t st, size_t bytes, fhe::u64 **out);
 int for_sub_batches(fhe_ctx *ctx, hipStream_t st, size_t n_poly, size_t per, size_t side_tmp_bytes,

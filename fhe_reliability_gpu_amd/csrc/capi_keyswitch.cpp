@@ -268,7 +268,7 @@ static int ks_mac(fhe_ctx *ctx, fhe_keyswitch *p, const uint64_t *d_c, const uin
     const KsShard &sh = p->sh;
     const size_t MO = p->m_own;
     const LimbParams *lp = t->d_lp.as<LimbParams>();
-    u64 *ext = p->ext.as<u64>(), *acc = p->acc.as<u64>();
+    u64 *ext = p->ext.as<u64>(), *acc = p->acc_cur();
     hipError_t e;
     if (!MO) return FHE_OK;
     TraceScope tr_mk(ctx, st, "MULTEVK");
@@ -349,7 +349,7 @@ static int ks_finish(fhe_ctx *ctx, fhe_keyswitch *p, uint64_t *d_out0, uint64_t 
     if (!sh.cn) return FHE_OK;
     const size_t N = (size_t)1 << p->log_n, MO = p->m_own;
     const LimbParams *lp = t->d_lp.as<LimbParams>();
-    u64 *acc = p->acc.as<u64>(), *conv = p->conv.as<u64>();
+    u64 *acc = p->acc_cur(), *conv = p->conv_cur();
     int rc;
     hipError_t e;
     const bool plain = !ks_fast_path(ctx, p);
@@ -358,7 +358,7 @@ static int ks_finish(fhe_ctx *ctx, fhe_keyswitch *p, uint64_t *d_out0, uint64_t 
     const bool trivial = p->K == 1 && p->log_n >= 13 && !plain;
     if (galois_acc && plain) return fail(FHE_ERR_UNSUPPORTED, "hoisted rotations need the fused mod-down tail");
     if (!trivial) {
-        e = launch_baseconv_exact_jobs(st, (sp_hoist ? p->hdown_jobs : p->down_jobs).as<BcJob>(), 2, p->down->dev.m, p->down->dev.k, p->down->dev.f64 != 0, N, p->down->dev.m <= 16 ? 1u << (p->down->dev.m - 1) : 0u);
+        e = launch_baseconv_exact_jobs(st, (sp_hoist ? (p->cur ? p->hdown_jobs2 : p->hdown_jobs) : p->down_jobs).as<BcJob>(), 2, p->down->dev.m, p->down->dev.k, p->down->dev.f64 != 0, N, p->down->dev.m <= 16 ? 1u << (p->down->dev.m - 1) : 0u);
         if (e != hipSuccess) return hip_fail(e, "launch_baseconv_exact_jobs");
         if (p->plain_modulus && (rc = fhe_scalar_affine(ctx, conv, conv, p->t_mod_Q.data() + sh.clo, nullptr, t, 2, sh.cn, sh.clo, st))) return rc;
     }
@@ -585,6 +585,14 @@ static int hoist_buffers(fhe_ctx *ctx, fhe_keyswitch *p)
     for (int h = 0; h < 2; h++)
         down.push_back(BcJob{p->down->dev, p->hsp.as<u64>(), p->conv.as<u64>() + (size_t)h * p->sh.cn * N, 0xFFFFFFFFu, 0u, p->hdown_rows.as<u32>() + (size_t)h * K});
     HIP_TRY(p->hdown_jobs.upload(down));
+    // the second set (rotations on the side stream)
+    HIP_TRY(p->acc2.alloc(p->acc.bytes));
+    HIP_TRY(p->conv2.alloc(p->conv.bytes));
+    HIP_TRY(p->hsp2.alloc(2 * K * N * 8));
+    std::vector<BcJob> down2;
+    for (int h = 0; h < 2; h++)
+        down2.push_back(BcJob{p->down->dev, p->hsp2.as<u64>(), p->conv2.as<u64>() + (size_t)h * p->sh.cn * N, 0xFFFFFFFFu, 0u, p->hdown_rows.as<u32>() + (size_t)h * K});
+    HIP_TRY(p->hdown_jobs2.upload(down2));
     return FHE_OK;
 }
 
@@ -628,31 +636,50 @@ extern "C" int fhe_rotate_hoisted(fhe_ctx *ctx, fhe_keyswitch *p, uint64_t *cons
         if ((rc = ks_begin(ctx, p, d_c1, st))) return rc;
         if ((rc = ks_extend(ctx, p, st, fused))) return rc;
     }
-    u64 *acc = p->acc.as<u64>(), *hsp = p->hsp.as<u64>();
-    for (size_t r = 0; r < n_rot; r++) {
-        TraceScope tr(ctx, st, "ROTATE", true);
+    // Rotations alternate between the caller's stream and the context's side stream (fork / join by events; not inside a stream capture,
+    // not while tracing): a rotation's conversions (FP64 issue-bound) and small transforms run under the next one's inner product
+    // (memory-bound).  Each stream has its own sums / special limbs / converted limbs; the shared digits are read-only.
+    fhe_ctx::Side *sd = nullptr;
+    if (n_rot > 1 && ctx->split != 0 && !ctx->trace_on) {
+        if ((rc = side_stream(ctx, st, &sd))) return rc;
+        if (sd) {
+            HIP_TRY(hipEventRecord(sd->fork, st));
+            HIP_TRY(hipStreamWaitEvent(sd->s, sd->fork, 0));
+        }
+    }
+    rc = FHE_OK;
+    for (size_t r = 0; r < n_rot && !rc; r++) {
+        p->cur = sd ? (int)(r & 1) : 0;
+        hipStream_t s = p->cur ? sd->s : st;
+        u64 *acc = p->acc_cur(), *hsp = p->hsp_cur();
+        TraceScope tr(ctx, s, "ROTATE", true);
         const u32 g = galois_elts[r];
-        if ((rc = ks_mac(ctx, p, d_c1, d_prepared_keys[r], st, fused))) return rc;
-        TraceScope tr_ms(ctx, st, "MODSWITCH");
+        if ((rc = ks_mac(ctx, p, d_c1, d_prepared_keys[r], s, fused))) break;
+        TraceScope tr_ms(ctx, s, "MODSWITCH");
         // INTT of sigma(special limbs of the sums), out of place: acc ([2][M][N], special limbs from row L) -> hsp ([2][K][N])
         {
-            TraceScope tr_ntt(ctx, st, "NTT");
+            TraceScope tr_ntt(ctx, s, "NTT");
             rc = for_each_run(t, K, L, [&](size_t off, size_t len, int path) -> int {
                 PassArgs a{hsp + off * N, lp, (u32)(L + off), (u32)len, (u32)(2 * len), (u32)K, nullptr};
                 a.src = acc + (L + off) * N;
                 a.src_stride = (u32)MO;
                 a.galois = g;
-                hipError_t e2 = launch_ntt(st, a, p->log_n, true, path, 1);
+                hipError_t e2 = launch_ntt(s, a, p->log_n, true, path, 1);
                 return e2 == hipSuccess ? FHE_OK : hip_fail(e2, "launch_ntt");
             });
-            if (rc) return rc;
+            if (rc) break;
         }
         if (p->plain_modulus)
-            for (int h = 0; h < 2; h++)
-                if ((rc = fhe_scalar_affine(ctx, hsp + (size_t)h * K * N, hsp + (size_t)h * K * N, p->t_inv_P.data(), nullptr, t, 1, K, L, st))) return rc;
-        if ((rc = ks_finish(ctx, p, d_out0[r], d_out1[r], d_c0, nullptr, st, g, hsp))) return rc;
+            for (int h = 0; h < 2 && !rc; h++)
+                rc = fhe_scalar_affine(ctx, hsp + (size_t)h * K * N, hsp + (size_t)h * K * N, p->t_inv_P.data(), nullptr, t, 1, K, L, s);
+        if (!rc) rc = ks_finish(ctx, p, d_out0[r], d_out1[r], d_c0, nullptr, s, g, hsp);
     }
-    return FHE_OK;
+    p->cur = 0;
+    if (sd) {       // join even after a failed launch: the side stream must not be left forked
+        HIP_TRY(hipEventRecord(sd->join, sd->s));
+        HIP_TRY(hipStreamWaitEvent(st, sd->join, 0));
+    }
+    return rc;
 }
 
 // Hoisted rotations on a limb-sharded plan: the input's all-gather (gather 1) and the digit extension are shared by all Galois elements,
