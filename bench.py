@@ -804,6 +804,31 @@ def main():
                 "note": "fhe_rotate_hoisted: INTT + digit extension + column pass of the input once, per element the inner product and the mod-down"}}
         also.update(hoisted_rates())
 
+        def bsgs_rate():
+            # the whole baby-step / giant-step product (fhe_bsgs_matvec; profile_framewk/src/matmul_ckks.cpp:45-113) at the config-5 shape:
+            # n1 = 8 baby steps (7 hoisted rotations), n2 = 4 giant steps (3 plain rotations), 32 diagonals; parity: tests/test_gpu_hoisted.py
+            logn, L, K, dnum, n1, n2 = 16, 44, 11, 4, 8, 4
+            n = 1 << logn
+            qk = F.create_moduli(n, [args.bits] * (L + K))
+            tk = eng.tables(logn, qk)
+            ks = F.KeySwitch(eng, tk, L, K, dnum)
+            mk = lambda *shape: torch.randint(0, qk[0], shape, generator=g, device="cuda", dtype=torch.int64)
+            c0, c1, key = mk(L, n), mk(L, n), mk(dnum, 2, L + K, n)
+            diags = mk(n2, n1, L, n)
+            y0, y1 = torch.empty((L, n), dtype=torch.int64, device="cuda"), torch.empty((L, n), dtype=torch.int64, device="cuda")
+            be = (C.c_uint32 * (n1 - 1))(*[pow(3, b, 2 * n) for b in range(1, n1)])
+            ge = (C.c_uint32 * (n2 - 1))(*[pow(3, gg * n1, 2 * n) for gg in range(1, n2)])
+            bk = (C.c_void_p * (n1 - 1))(*[key.data_ptr()] * (n1 - 1))
+            gk = (C.c_void_p * (n2 - 1))(*[key.data_ptr()] * (n2 - 1))
+            call = lambda: check(lib.fhe_bsgs_matvec(eng._h, ks._h, P(y0), P(y1), P(c0), P(c1), P(diags), n1, n2, be, bk, ge, gk, sptr))
+            ms = timed_loop(call, 12, 4)
+            del ks, key, diags
+            return {"bsgs_matvec_N=2^16_L44_K11_dnum4_n1=8_n2=4": {
+                "ms_per_product_device": ms, "rotations_per_product": n1 + n2 - 2, "diagonals": n1 * n2,
+                "us_per_rotation_equivalent": ms * 1e3 / (n1 + n2 - 2),
+                "note": "7 hoisted baby rotations (two streams), 4 inner sums of 8 diagonal products, 3 plain giant rotations accumulated"}}
+        also.update(bsgs_rate())
+
         def fourstep_rate():
             # four_step_ntt (reliability_test/four_step_ntt_prot.py:71-109), MOD = 998244353, as a batch: two launches for all
             # vectors; 2^16 = 256 x 256 and 2^17 = 512 x 256 (the n1 != n2 case of BASELINE configs[3]); 16 N bytes per vector

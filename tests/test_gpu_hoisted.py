@@ -244,3 +244,53 @@ def test_bsgs_matvec_on_a_trivial_ciphertext_is_the_plaintext_formula(F, eng):
     assert (o0.download() == want).all()
     assert not o1.download().any()
     eng.check()
+
+
+def test_hoisted_rotations_one_stream_two_streams_and_capture_agree(F, eng):
+    """fhe_rotate_hoisted alternates its rotations between the caller's stream and the context's side stream (second buffer set);
+    with the side stream switched off ("ntt_split" 0) and inside a stream capture (where it must not fork) the words are the same."""
+    import torch
+    from fhe_reliability_gpu_amd._lib import check, lib
+    logn, L, K, dnum, n_rot = 13, 4, 2, 2, 5
+    n = 1 << logn
+    qk = F.create_moduli(n, [50] * (L + K))
+    tk = eng.tables(logn, qk)
+    ks = F.KeySwitch(eng, tk, L, K, dnum)
+    g = torch.Generator(device="cuda")
+    g.manual_seed(3)
+    mk = lambda *shape: torch.randint(0, qk[0], shape, generator=g, device="cuda", dtype=torch.int64)
+    c0, c1 = mk(L, n), mk(L, n)
+    keys = [mk(dnum, 2, L + K, n) for _ in range(n_rot)]
+    elts = [pow(3, b + 1, 2 * n) for b in range(n_rot)]
+    o0 = [torch.zeros((L, n), dtype=torch.int64, device="cuda") for _ in range(n_rot)]
+    o1 = [torch.zeros((L, n), dtype=torch.int64, device="cuda") for _ in range(n_rot)]
+    vp_t = C.c_void_p * n_rot
+    a0, a1 = vp_t(*[x.data_ptr() for x in o0]), vp_t(*[x.data_ptr() for x in o1])
+    kk, ge = vp_t(*[k.data_ptr() for k in keys]), (C.c_uint32 * n_rot)(*elts)
+    P = lambda x: C.c_void_p(x.data_ptr())
+
+    def call(s):
+        check(lib.fhe_rotate_hoisted(eng._h, ks._h, a0, a1, P(c0), P(c1), ge, kk, n_rot, C.c_void_p(s.cuda_stream)))
+
+    s = torch.cuda.Stream()
+    call(s)
+    torch.cuda.synchronize()
+    want = [(x.clone(), y.clone()) for x, y in zip(o0, o1)]
+    eng.set_option("ntt_split", 0)
+    try:
+        for x in o0 + o1:
+            x.zero_()
+        call(s)
+        torch.cuda.synchronize()
+        assert all(bool((x == w[0]).all()) and bool((y == w[1]).all()) for x, y, w in zip(o0, o1, want))
+    finally:
+        eng.set_option("ntt_split", -1)
+    graph, cap = torch.cuda.CUDAGraph(), torch.cuda.Stream()
+    with torch.cuda.graph(graph, stream=cap):
+        call(cap)
+    for x in o0 + o1:
+        x.zero_()
+    graph.replay()
+    torch.cuda.synchronize()
+    assert all(bool((x == w[0]).all()) and bool((y == w[1]).all()) for x, y, w in zip(o0, o1, want))
+    eng.check()
