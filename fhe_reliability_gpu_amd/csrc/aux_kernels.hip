@@ -787,13 +787,13 @@ __global__ __launch_bounds__(256) void k_sub_scale(SubScaleArgs p)
 {
     const u32 h = blockIdx.y;
     u64 *out = h ? p.out1 : p.out0;
-    const u64 *a = p.a + (u64)h * p.a_stride, *b = p.b + (u64)h * p.b_stride, *add = h ? p.add1 : p.add0;
+    const u64 *a = p.a ? p.a + (u64)h * p.a_stride : nullptr, *b = p.b ? p.b + (u64)h * p.b_stride : nullptr, *add = h ? p.add1 : p.add0;
     const u64 total = (u64)p.limbs << p.logn;
     for (u64 i = blockIdx.x * (u64)blockDim.x + threadIdx.x; i < total; i += (u64)gridDim.x * blockDim.x) {
         const u32 l = (u32)(i >> p.logn);
         const LimbParams &lp = p.lp[p.limb0 + l];
         const u64 q = lp.q, r0 = lp.barrett_lo, r1 = lp.barrett_hi;
-        const u64 x = barrett128(a[i], 0, q, r0, r1), y = barrett128(b[i], 0, q, r0, r1);
+        const u64 x = a ? barrett128(a[i], 0, q, r0, r1) : 0, y = b ? barrett128(b[i], 0, q, r0, r1) : 0;     // (a or b absent: zero)
         const u64 d = x >= y ? x - y : x + q - y;
         u64 v = mulmod_b(d, p.scal[l], q, r0, r1);
         if (add) {

@@ -405,6 +405,7 @@ int fhe_ctx_create(int device, fhe_ctx **out)
     if (const char *v = getenv("FHE_NTT_SPLIT")) c->split = atoi(v) < 0 ? -1 : atoi(v) ? 1 : 0;
     if (const char *v = getenv("FHE_NTT_CHUNK_MIB")) c->chunk_mib = (unsigned)std::max(0, atoi(v));
     if (const char *v = getenv("FHE_KS_FUSED")) c->ks_fused = atoi(v) < 0 ? -1 : atoi(v) ? 1 : 0;
+    if (const char *v = getenv("FHE_HMULT_FUSED_RESCALE")) c->hmult_fused_rescale = atoi(v) != 0;
     *out = c.release();
     return FHE_OK;
 }
@@ -448,6 +449,7 @@ int fhe_ctx_set_option(fhe_ctx *ctx, const char *name, long value)
     else if (!std::strcmp(name, "ntt_pingpong")) ctx->pingpong = value < 0 ? -1 : value ? 1 : 0;
     else if (!std::strcmp(name, "ntt_chunk_mib")) ctx->chunk_mib = (unsigned)std::max(0l, value);
     else if (!std::strcmp(name, "ks_fused")) ctx->ks_fused = value < 0 ? -1 : value ? 1 : 0;
+    else if (!std::strcmp(name, "hmult_fused_rescale")) ctx->hmult_fused_rescale = value != 0;
     else if (!std::strcmp(name, "ntt_only_pass")) ctx->only_pass = value == 0 ? 0 : value == 1 ? 1 : -1;   // bench.py times each kernel with it
     else if (!std::strcmp(name, "fused_skip_teams")) ctx->fused_skip_teams = (unsigned)value;   // test hook
     else return fail(FHE_ERR_INVALID, "unknown option");

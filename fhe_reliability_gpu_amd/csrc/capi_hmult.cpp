@@ -186,6 +186,11 @@ int fhe_hmult(fhe_ctx *ctx, fhe_keyswitch *p, uint64_t *d_out0, uint64_t *d_out1
     int rc;
     if ((rc = fhe_tensor_product(ctx, d0, d1, d2, d_a0, d_a1, d_b0, d_b1, p->t, L, 0, stream))) return rc;
     if (!rescale) return fhe_relinearize(ctx, p, d_out0, d_out1, d0, d1, d2, d_relin_key, stream);
+    if (ks_rescale_fusable(ctx, p)) {
+        // the mod-down and the rescale share one forward transform (capi_keyswitch.cpp ks_finish_rescale): same words as the two steps below
+        HIP_TRY(hipSetDevice(ctx->device));
+        return keyswitch_core(ctx, p, d_out0, d_out1, d2, d_relin_key, d0, d1, stream, true);
+    }
     if ((rc = fhe_relinearize(ctx, p, pre, pre + L * N, d0, d1, d2, d_relin_key, stream))) return rc;
     uint64_t *outs[3] = {d_out0, d_out1, nullptr};
     return rescale_core(ctx, p, outs, pre, 2, stream);

@@ -100,6 +100,7 @@ struct fhe_ctx {
     bool packed_on = false;   // "ntt_packed"
     int mode = 0;          // 0 = two launches per transform (default), 1 = fused launch (experimental)
     unsigned fused_dist = 4, fused_wgs = 768;
+    bool hmult_fused_rescale = true;   // fhe_hmult: mod-down and rescale behind one forward transform (FHE_HMULT_FUSED_RESCALE=0: the two steps apart)
     unsigned fused_skip_teams = 0;
     bool trace_on = false;
     std::string trace;          // collected trace text (fhe_ctx_trace)
@@ -184,6 +185,7 @@ struct fhe_keyswitch {
     DevBuf qlast_inv;                  // q_{L-1}^-1 mod q_j, owned j < L-1
     DevBuf rs_last, rs_delta, rs_jobs; // rs_last backs rs_bc on one device; [3][rs_n][N] residues; job list (3 parts)
     DevBuf hm, hm_pre;                 // [3][L][N] tensor product, [2][L][N] relinearised product before the rescale
+    DevBuf pq_tw;                      // one device: P mod q_j as a twiddle of limb j's arithmetic, j < L (mod-down and rescale sharing one transform)
     DevBuf bsgs;                       // fhe_bsgs_matvec: baby rotations, inner sum, one rotated inner sum (grown on demand)
     // second set of per-rotation buffers: hoisted rotations alternate between the caller's stream and a side stream (one rotation's
     // conversions run under the next one's inner product); `cur` selects the set the host-side helpers address (launch arguments are
@@ -315,9 +317,11 @@ inline int ilog2_exact(u64 v)
 }
 
 
-// defined in capi_keyswitch.cpp: the key switch of d_c with d_add0 / d_add1 (optional, L x N) added to the two output parts
+// defined in capi_keyswitch.cpp: the key switch of d_c with d_add0 / d_add1 (optional, L x N) added to the two output parts;
+// rescale (only where ks_rescale_fusable() says so): the outputs are the (L-1)-limb parts after dropping q_{L-1} as well
 int keyswitch_core(fhe_ctx *ctx, fhe_keyswitch *p, uint64_t *d_out0, uint64_t *d_out1, const uint64_t *d_c, const uint64_t *d_evk,
-                   const uint64_t *d_add0, const uint64_t *d_add1, void *stream);
+                   const uint64_t *d_add0, const uint64_t *d_add1, void *stream, bool rescale = false);
+bool ks_rescale_fusable(const fhe_ctx *ctx, const fhe_keyswitch *p);
 // defined in capi.cpp
 int build_tables(fhe_ctx *ctx, int log_n, const fhe::u64 *q, int count, const fhe::u64 *fwd_rows, bool want_inverse, int force_path,
                  const fhe::u64 *psi_or_null, fhe_ntt_tables **out, const fhe::u64 *gs_scale = nullptr);

@@ -103,6 +103,15 @@ static int ks_create(fhe_ctx *ctx, const fhe_ntt_tables *t, int L, int K, int dn
             if (!pinv[j]) return fail(FHE_ERR_INVALID, "special primes must be coprime to the ciphertext primes");
         }
         HIP_TRY(p->pinv.upload(pinv));
+        if (!sharded) {
+            std::vector<Tw> pq(sh.cn);
+            for (int j = 0; j < sh.cn; j++) {
+                u64 pm = 1 % Q[j];
+                for (u64 pk : P) pm = host::mul_mod(pm, pk % Q[j], Q[j]);
+                pq[j] = t->path[j] == PATH_F64 ? ArithF64::encode(pm, Q[j]) : ArithU64::encode(pm, Q[j]);
+            }
+            HIP_TRY(p->pq_tw.upload(pq));
+        }
     }
     p->up_trivial = p->alpha == 1 && t->log_n >= 13;
     // every owned limb of every digit's extension except the digit's own limbs, one list per arithmetic path
@@ -288,7 +297,10 @@ static int ks_extend_mac(fhe_ctx *ctx, fhe_keyswitch *p, const uint64_t *d_c, co
 // opening of the mod-down (MODSWITCH, 16384_4:454-463): the owned special limbs of both halves to coefficient form -- in
 // place inside acc ([2][MO][N]) on one device, in this rank's slot of gather buffer 2 ([2][smax][N]) when sharded
 // galois != 0 (a hoisted rotation on a sharded plan): the sums are still in the un-rotated frame, sigma is taken on this INTT's load
-static int ks_special_intt(fhe_ctx *ctx, fhe_keyswitch *p, hipStream_t st, u32 galois = 0)
+// with_last (one device, ks_finish_rescale): the LAST ciphertext limb goes along -- its sums become acc P^-1 + add first (the limb
+// after the mod-down, up to the converted part that is subtracted in coefficient form later) and row L-1 of acc ends in coefficient form
+static int ks_special_intt(fhe_ctx *ctx, fhe_keyswitch *p, hipStream_t st, u32 galois = 0, bool with_last = false, const uint64_t *d_add0 = nullptr,
+                           const uint64_t *d_add1 = nullptr)
 {
     const fhe_ntt_tables *t = p->t;
     const KsShard &sh = p->sh;
@@ -298,6 +310,17 @@ static int ks_special_intt(fhe_ctx *ctx, fhe_keyswitch *p, hipStream_t st, u32 g
     u64 *acc = p->acc.as<u64>(), *sp = acc + (size_t)sh.cn * N;
     u32 stride = (u32)MO;
     int rc;
+    size_t first = sh.slo, count = sh.sn;
+    if (with_last) {
+        const size_t R = (size_t)p->L - 1;
+        const SubScaleArgs sa{acc + R * N, acc + (MO + R) * N, acc + R * N, nullptr, d_add0 ? d_add0 + R * N : nullptr, p->pinv.as<u64>() + R, (u64)(MO * N), 0, lp, (u32)R, 1u,
+                              p->log_n, d_add1 ? d_add1 + R * N : nullptr};
+        hipError_t e = launch_sub_scale(st, sa);
+        if (e != hipSuccess) return hip_fail(e, "launch_sub_scale");
+        sp -= N;
+        first -= 1;
+        count += 1;
+    }
     if (galois && (!p->sharded || p->log_n < 5)) return fail(FHE_ERR_UNSUPPORTED, "the Galois map on the special limbs' INTT needs the out-of-place (sharded) form and N >= 2^5");
     // sharded: out of place, from acc straight into this rank's slot of gather buffer 2 (round 2 copied the rows there first)
     const u64 *from = nullptr;
@@ -308,8 +331,8 @@ static int ks_special_intt(fhe_ctx *ctx, fhe_keyswitch *p, hipStream_t st, u32 g
     }
     {
         TraceScope tr_ntt(ctx, st, "NTT");
-        rc = for_each_run(t, sh.sn, sh.slo, [&](size_t off, size_t len, int path) -> int {
-            PassArgs a{sp + off * N, lp, (u32)(sh.slo + off), (u32)len, (u32)(2 * len), stride, nullptr};
+        rc = for_each_run(t, count, first, [&](size_t off, size_t len, int path) -> int {
+            PassArgs a{sp + off * N, lp, (u32)(first + off), (u32)len, (u32)(2 * len), stride, nullptr};
             if (from) {
                 a.src = from + off * N;
                 a.src_stride = (u32)MO;
@@ -387,15 +410,57 @@ static int ks_finish(fhe_ctx *ctx, fhe_keyswitch *p, uint64_t *d_out0, uint64_t 
     });
 }
 
+// Mod-down and rescale behind ONE forward transform (fhe_hmult with rescale, one device, CKKS form).  The sequence of the reference --
+// relinearize_inplace, then mod_switch_to_next_inplace (reliability_test/dotprod_test.cu:114-115) -- transforms the converted special
+// limbs X_j = NTT(conv_j), forms v_j = (acc_j - X_j) P^-1 + d_j, turns v_{L-1} to coefficient form y, transforms y mod q_j for every
+// remaining prime (Delta_j) and forms (v_j - Delta_j) q_last^-1.  The transform is linear: NTT(conv_j + P y) = X_j + P Delta_j and
+//   ((acc_j - NTT(conv_j + P y)) P^-1 + d_j) q_last^-1 = (v_j - Delta_j) q_last^-1,
+// the same residues, hence the same canonical words.  y itself needs no forward transform either: INTT(X_{L-1}) = conv_{L-1}, so
+//   y = INTT(acc_{L-1} P^-1 + d_{L-1}) - P^-1 conv_{L-1}  (mod q_{L-1}),
+// whose first term rides along with the special limbs' INTT (ks_special_intt, with_last).  What is left after the conversion: one
+// word-wise launch for y, ONE column pass that loads conv_j + (P mod q_j) (y mod q_j) (ColAddSrc) and ONE row pass whose tail ends with
+// the second factor (RowEpiArgs::scal2).  The full-width transform of the y residues, the L-limb intermediate and its re-read disappear.
+bool ks_rescale_fusable(const fhe_ctx *ctx, const fhe_keyswitch *p)
+{
+    return ctx->hmult_fused_rescale && !p->sharded && !p->plain_modulus && !ctx->trace_on && ks_fast_path(ctx, p) && p->log_n >= 13 && p->K >= 2 && p->L >= 2 && p->rs_n == p->L - 1 &&
+           p->pq_tw.bytes != 0;
+}
+
+static int ks_finish_rescale(fhe_ctx *ctx, fhe_keyswitch *p, uint64_t *d_out0, uint64_t *d_out1, const uint64_t *d_add0, const uint64_t *d_add1, hipStream_t st)
+{
+    const fhe_ntt_tables *t = p->t;
+    const size_t N = (size_t)1 << p->log_n, MO = p->m_own, L = p->L, R = L - 1;
+    const LimbParams *lp = t->d_lp.as<LimbParams>();
+    u64 *acc = p->acc_cur(), *conv = p->conv_cur();
+    hipError_t e = launch_baseconv_exact_jobs(st, p->down_jobs.as<BcJob>(), 2, p->down->dev.m, p->down->dev.k, p->down->dev.f64 != 0, N,
+                                              p->down->dev.m <= 16 ? 1u << (p->down->dev.m - 1) : 0u);
+    if (e != hipSuccess) return hip_fail(e, "launch_baseconv_exact_jobs");
+    {
+        // y = INTT(v_{L-1}) = INTT(acc P^-1 + d) - P^-1 conv_{L-1}: the first term sits in row L-1 of acc (ks_special_intt, with_last)
+        const SubScaleArgs sa{p->rs_bc, p->rs_bc + N, nullptr, conv + R * N, acc + R * N, p->pinv.as<u64>() + R, 0, (u64)(L * N), lp, (u32)R, 1u, p->log_n, acc + (MO + R) * N};
+        if ((e = launch_sub_scale(st, sa)) != hipSuccess) return hip_fail(e, "launch_sub_scale");
+    }
+    const ColAddSrc as{p->rs_bc, (u64)N, p->pq_tw.as<Tw>()};
+    return for_each_run(t, R, 0, [&](size_t off, size_t len, int path) -> int {
+        PassArgs a{conv + off * N, lp, (u32)off, (u32)len, (u32)(2 * len), (u32)L};
+        RowEpiArgs ep{{d_out0 + off * N, d_out1 + off * N, nullptr}, {d_add0 ? d_add0 + off * N : nullptr, d_add1 ? d_add1 + off * N : nullptr, nullptr},
+                      acc + off * N, (u64)(MO * N), p->pinv.as<u64>() + off};
+        ep.scal2 = p->qlast_inv.as<u64>() + off;
+        hipError_t e2 = launch_ntt_subscale(st, a, ep, p->log_n, path, &as);
+        return e2 == hipSuccess ? FHE_OK : hip_fail(e2, "launch_ntt_subscale");
+    });
+}
+
 // Hybrid RNS key switching on one device, operation order of the reference's SEAL trace (profile_framewk/build/data/ckks/16384_4:466-539)
 // with the launches batched.  d_add0 / d_add1 (optional, L x N): added to the output parts -- a rotation passes sigma(c0), a
 // relinearisation d0 and d1.
 int keyswitch_core(fhe_ctx *ctx, fhe_keyswitch *p, uint64_t *d_out0, uint64_t *d_out1, const uint64_t *d_c, const uint64_t *d_evk,
-                   const uint64_t *d_add0, const uint64_t *d_add1, void *stream)
+                   const uint64_t *d_add0, const uint64_t *d_add1, void *stream, bool rescale)
 {
     if (!ctx || !p || !d_out0 || !d_out1 || !d_c || !d_evk) return fail(FHE_ERR_INVALID, "null argument");
     if (p->sharded)
         return fail(FHE_ERR_INVALID, "a sharded plan runs through fhe_keyswitch_shard_begin / _inner / _finish with the all-gathers between them");
+    if (rescale && !ks_rescale_fusable(ctx, p)) return fail(FHE_ERR_UNSUPPORTED, "this plan rescales in a separate step");
     HIP_TRY(hipSetDevice(ctx->device));
     hipStream_t st = pick(ctx, stream);
     int rc;
@@ -403,7 +468,8 @@ int keyswitch_core(fhe_ctx *ctx, fhe_keyswitch *p, uint64_t *d_out0, uint64_t *d
     if ((rc = ks_begin(ctx, p, d_c, st))) return rc;
     if ((rc = ks_extend_mac(ctx, p, d_c, d_evk, st))) return rc;
     TraceScope tr_ms(ctx, st, "MODSWITCH");
-    if ((rc = ks_special_intt(ctx, p, st))) return rc;
+    if ((rc = ks_special_intt(ctx, p, st, 0, rescale, d_add0, d_add1))) return rc;
+    if (rescale) return ks_finish_rescale(ctx, p, d_out0, d_out1, d_add0, d_add1, st);
     return ks_finish(ctx, p, d_out0, d_out1, d_add0, d_add1, st);
 }
 

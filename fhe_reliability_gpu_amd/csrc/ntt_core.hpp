@@ -221,6 +221,9 @@ template <class P> FHE_HD u64 pk_extract(P w, u32 idx)
 // conversion to the arithmetic's element type) and every final word it writes, with the element's index
 // relative to the tile base.  The ABFT detector hangs its weighted checksums here (ntt_kernels.hip), so
 // that checking a transform costs arithmetic only, not two more sweeps over the data.
+// (a tap that declares PRELOAD = true instead offers load(idx) / apply(x, word, ctx): a second input of the pass, see AddSrcTap)
+template <class T, class = void> struct tap_preloads { static constexpr bool value = false; };
+template <class T> struct tap_preloads<T, decltype((void)T::PRELOAD)> { static constexpr bool value = T::PRELOAD; };
 struct NoTap {
     static constexpr bool ACTIVE = false;
     static constexpr bool MID = false;    // MID: the tap also sees the lazy words a column pass hands to the next launch
@@ -286,10 +289,21 @@ struct ColPass {
                     const u64 *from = ldb + (size_t)(g0 + ((u32)r << LOGS)) * STRIDE + col;
                     raw[r] = COHERENT_IN == 1 ? load_coherent_u64(from) : (COHERENT_IN == 2 || (STREAM && IN_MODE == IO_CANONICAL)) ? load_stream_u64(from) : *from;
                 }
-                convert_in<A, R, IN_MODE>(x, raw, c);
-                if constexpr (TAP::ACTIVE) {
+                if constexpr (tap_preloads<TAP>::value) {
+                    // a tap with a second input: its words are requested together with the tile's, before anything waits
+                    u64 extra[R];
 #pragma unroll
-                    for (int r = 0; r < R; r++) tap->in((g0 + ((u32)r << LOGS)) * STRIDE + col, x[r], c);
+                    for (int r = 0; r < R; r++) extra[r] = tap->load((g0 + ((u32)r << LOGS)) * STRIDE + col);
+                    convert_in<A, R, IN_MODE>(x, raw, c);
+                    tap->prepare(extra, c);
+#pragma unroll
+                    for (int r = 0; r < R; r++) tap->apply(x[r], extra[r], c);
+                } else {
+                    convert_in<A, R, IN_MODE>(x, raw, c);
+                    if constexpr (TAP::ACTIVE) {
+#pragma unroll
+                        for (int r = 0; r < R; r++) tap->in((g0 + ((u32)r << LOGS)) * STRIDE + col, x[r], c);
+                    }
                 }
             } else {
 #pragma unroll

@@ -820,6 +820,7 @@ struct SubScaleTap {
     u32 pos0, galois;           // (index of the tile's first word inside its limb; a rotation's sigma(c0), RowEpiArgs::galois)
     int logn;
     const u64 *acc_limb;        // != nullptr: `acc` too is read through the Galois map, from this limb base (RowEpiArgs::galois_a)
+    u64 scal2;                  // 0 = none: the finished word is multiplied by it (RowEpiArgs::scal2 -- the rescale after a mod-down)
     template <class E, class C> FHE_D void in(u32, E, const C &) {}
     // integer form (ArithU64 limbs; any 64-bit words)
     FHE_D u64 one_int(u64 a, u64 x, u64 t, bool has_add) const
@@ -832,6 +833,7 @@ struct SubScaleTap {
             v += t < q ? t : barrett128(t, 0, q, r0, r1);
             v = v >= q ? v - q : v;
         }
+        if (scal2) v = barrett128(v * scal2, mulhi64(v, scal2), q, r0, r1);
         return v;
     }
     // FP64 form: every word canonical (x is the pass's own output; a and t are checked by the caller)
@@ -847,6 +849,10 @@ struct SubScaleTap {
         const double sw = ArithF64::from_canonical(scal);
         double v = ArithF64::mulmod_w(d, sw, sw * ninv, c);            // |v| < 0.9 q
         if (has_add) v += ArithF64::from_canonical(t);
+        if (scal2) {
+            const double s2 = ArithF64::from_canonical(scal2);
+            v = ArithF64::mulmod_w(v, s2, s2 * ninv, c);               // |v| < 1.9 q going in
+        }
         return ArithF64::canonical(v, c);
     }
     FHE_D void store(u32 idx, u64 x0, u64 x1)
@@ -873,6 +879,68 @@ struct SubScaleTap {
     }
 };
 
+// Column pass of that transform with a second input (ColAddSrc): every word it loads becomes x + w_l * y (mod q_l), y read from the
+// part's ONE extra limb at the same position.  The sum is folded back right away, so the pass's lazy-range schedule sees an input no
+// larger than a canonical one.
+template <class A>
+struct AddSrcTap {
+    static constexpr bool ACTIVE = true;
+    static constexpr bool MID = false;
+    static constexpr bool STORES = false;
+    static constexpr bool PRELOAD = true;
+    const u64 *y;               // the tile's first word inside the part's extra limb
+    Tw w;
+    FHE_D u64 load(u32 idx) const { return y[idx]; }
+    // one cold branch for the whole register set (FP64 limbs under an extra limb of the integer path: words up to 2^61)
+    template <int R> FHE_D void prepare(u64 (&e)[R], const typename A::Ctx &c) const
+    {
+        if constexpr (A::PATH == PATH_F64) {
+            bool big = false;
+#pragma unroll
+            for (int r = 0; r < R; r++) big |= (e[r] >> 52) != 0;
+            if (__builtin_expect(big, 0)) {
+#pragma unroll
+                for (int r = 0; r < R; r++) e[r] = (e[r] >> 52) ? reduce_any_u64(e[r], c.q) : e[r];
+            }
+        }
+    }
+    FHE_D void apply(typename A::elem &x, u64 v, const typename A::Ctx &c) const
+    {
+        if constexpr (A::PATH == PATH_F64) {
+            x += A::mulmod(A::from_canonical(v), w, c);                               // v < 2^52: exact; |.| < 1.6 q
+            A::reduce(x, c);
+        } else {
+            x += A::mulmod(v, w, c);                                                   // [0, 3q): inside the forward butterflies' [0, 4q)
+        }
+    }
+};
+
+template <class PASS, int LOGN>
+__global__ __launch_bounds__(NTT_THREADS) void k_ntt_col_addsrc(PassArgs a, ColAddSrc s)
+{
+    typedef typename PASS::Arith A;
+    __shared__ __attribute__((aligned(16))) typename PASS::elem lds[PASS::LDS_ELEMS > 0 ? PASS::LDS_ELEMS : 1];
+    u32 limb;
+    u64 *base = col_tile<PASS, LOGN>(blockIdx.x, a, limb);
+    const u32 unit = blockIdx.x / PASS::TILES, tile = blockIdx.x % PASS::TILES, polys = a.units / a.limbs;
+    const LimbParams &p = a.lp[limb];
+    const typename A::Ctx ctx = A::make_ctx(p);
+    const TwPtr tw = as_global(p.fwd);
+    const Tw inv_n = p.inv_n;
+    const int tid = threadIdx.x;
+    AddSrcTap<A> tap{s.y + (size_t)(unit % polys) * s.y_stride + (size_t)tile * PASS::TCOLS, s.w[limb]};
+    const u64 *from = pass_source<PASS, LOGN, true>(a, base, 0u);
+    PASS::template phase<0>(tid, base, lds, tw, 0u, ctx, inv_n, &tap, from);
+    if constexpr (PASS::NPHASE > 1) {
+        __syncthreads();
+        PASS::template phase<1>(tid, base, lds, tw, 0u, ctx, inv_n);
+    }
+    if constexpr (PASS::NPHASE > 2) {
+        __syncthreads();
+        PASS::template phase<2>(tid, base, lds, tw, 0u, ctx, inv_n);
+    }
+}
+
 template <class PASS, int LOGN>
 __global__ __launch_bounds__(NTT_THREADS) void k_ntt_row_subscale(PassArgs a, RowEpiArgs ep)
 {
@@ -890,7 +958,7 @@ __global__ __launch_bounds__(NTT_THREADS) void k_ntt_row_subscale(PassArgs a, Ro
     const size_t eoff = ((size_t)l << LOGN) + (size_t)row0 * PASS::NPTS;      // element offset inside part h
     SubScaleTap<A> tap{ep.a + (size_t)h * ep.a_stride + eoff, ep.add[h] ? ep.add[h] + eoff : nullptr, ep.out[h] + eoff, ep.scal[l], p.q, p.barrett_lo, p.barrett_hi,
                        ep.pre ? ep.pre[l] : 0, p.n, p.ninv, ep.add[h] ? ep.add[h] + ((size_t)l << LOGN) : nullptr, row0 * (u32)PASS::NPTS, ep.galois, LOGN,
-                       ep.galois && ep.galois_a ? ep.a + (size_t)h * ep.a_stride + ((size_t)l << LOGN) : nullptr};
+                       ep.galois && ep.galois_a ? ep.a + (size_t)h * ep.a_stride + ((size_t)l << LOGN) : nullptr, ep.scal2 ? ep.scal2[l] : 0};
     const u64 *from = pass_source<PASS, LOGN, false>(a, base, row0);
     PASS::template phase<0>(tid, base, lds, tw, row0, ctx, inv_n, &tap, from);
     if constexpr (PASS::NPHASE > 1) {
@@ -908,14 +976,21 @@ __global__ __launch_bounds__(NTT_THREADS) void k_ntt_row_subscale(PassArgs a, Ro
 }
 
 template <class A, int LOGN>
-static hipError_t launch_subscale_t(hipStream_t st, const PassArgs &a, const RowEpiArgs &ep)
+static hipError_t launch_subscale_t(hipStream_t st, const PassArgs &a, const RowEpiArgs &ep, const ColAddSrc *add_src)
 {
     constexpr int GEO = LOGN >= 13 ? 1 : 0;
     typedef Passes<A, LOGN, false, GEO> PS;
     if constexpr (!PS::G::TWO_PASS) {
+        if (add_src) return hipErrorInvalidValue;
         hipLaunchKernelGGL((k_ntt_row_subscale<typename PS::Single, LOGN>), dim3(a.units * PS::Single::TILES), dim3(NTT_THREADS), 0, st, a, ep);
     } else {
-        hipError_t e = launch_pass<typename PS::Col, LOGN, false, true>(st, a);
+        hipError_t e;
+        if (add_src) {
+            hipLaunchKernelGGL((k_ntt_col_addsrc<typename PS::Col, LOGN>), dim3(a.units * PS::Col::TILES), dim3(NTT_THREADS), 0, st, a, *add_src);
+            e = hipGetLastError();
+        } else {
+            e = launch_pass<typename PS::Col, LOGN, false, true>(st, a);
+        }
         if (e != hipSuccess) return e;
         PassArgs second = a;
         second.src = nullptr;
@@ -926,13 +1001,13 @@ static hipError_t launch_subscale_t(hipStream_t st, const PassArgs &a, const Row
 
 bool ntt_subscale_supported(int logn) { return logn >= 5 && logn <= NTT_MAX_LOGN; }
 
-hipError_t launch_ntt_subscale(hipStream_t st, const PassArgs &a, const RowEpiArgs &ep, int logn, int path)
+hipError_t launch_ntt_subscale(hipStream_t st, const PassArgs &a, const RowEpiArgs &ep, int logn, int path, const ColAddSrc *add_src)
 {
     if (a.units == 0) return hipSuccess;
     if (a.map || !ntt_subscale_supported(logn) || a.units / a.limbs > 3) return hipErrorInvalidValue;
     switch (logn) {
 #define FHE_CASE(L) \
-    case L: return path == PATH_F64 ? launch_subscale_t<ArithF64, L>(st, a, ep) : launch_subscale_t<ArithU64, L>(st, a, ep);
+    case L: return path == PATH_F64 ? launch_subscale_t<ArithF64, L>(st, a, ep, add_src) : launch_subscale_t<ArithU64, L>(st, a, ep, add_src);
         FHE_CASE(5) FHE_CASE(6) FHE_CASE(7) FHE_CASE(8) FHE_CASE(9) FHE_CASE(10) FHE_CASE(11) FHE_CASE(12) FHE_CASE(13)
         FHE_CASE(14) FHE_CASE(15) FHE_CASE(16) FHE_CASE(17) FHE_CASE(18) FHE_CASE(19) FHE_CASE(20)
 #undef FHE_CASE

@@ -30,9 +30,18 @@ struct RowEpiArgs {
     const u64 *pre = nullptr;   // optional per-limb factor applied to the transformed words first (t of the BGV forms)
     u32 galois = 0;             // != 0: the addends are sigma_k(add[h]), read through the NTT-domain Galois map (a rotation's sigma(c0))
     u32 galois_a = 0;           // != 0 (with galois): `a` is read through the same map too -- a hoisted rotation's sums, formed in the un-rotated frame
+    const u64 *scal2 = nullptr; // optional second per-limb factor applied LAST: out = ((a - X) scal + add) scal2 (mod-down and rescale in one tail)
+};
+// Optional second input of the transform (two-launch sizes): the column pass loads data_h[l] + w[l] * y_h (mod q_l) instead of
+// data_h[l]; y_h = y + h * y_stride words is ONE limb per part (residues of some other prime, any 64-bit words), w = per TABLE limb
+// factors in the limb's twiddle encoding.  By linearity NTT(data + w y) = NTT(data) + w NTT(y): two subtractions share one transform.
+struct ColAddSrc {
+    const u64 *y;
+    u64 y_stride;
+    const Tw *w;
 };
 bool ntt_subscale_supported(int logn);
-hipError_t launch_ntt_subscale(hipStream_t st, const PassArgs &a, const RowEpiArgs &ep, int logn, int path);
+hipError_t launch_ntt_subscale(hipStream_t st, const PassArgs &a, const RowEpiArgs &ep, int logn, int path, const ColAddSrc *add_src = nullptr);
 
 // c = a * b mod (x^N + 1, q_l): forward column passes, one launch that finishes both forward transforms,
 // multiplies and starts the inverse, inverse column pass.  a and b are scratch afterwards.
@@ -130,7 +139,8 @@ struct ModConst {
 hipError_t launch_bitrev_scale(hipStream_t st, u64 *dst, const u64 *src, int logn, u32 units, const ModConst &mc, u64 scale,
                                bool do_scale);
 // out_h = (a_h - b_h) * scal[l] (+ add_h) mod q_l over `limbs` limbs from table index limb0, for one half
-// (out1 == nullptr) or both halves of a key switch in one launch; a_h = a + h * a_stride, b_h = b + h * b_stride (in words)
+// (out1 == nullptr) or both halves of a key switch in one launch; a_h = a + h * a_stride, b_h = b + h * b_stride (in words);
+// a == nullptr / b == nullptr: that operand is zero
 struct SubScaleArgs {
     u64 *out0, *out1;
     const u64 *a, *b, *add0, *scal;

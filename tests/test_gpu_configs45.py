@@ -115,6 +115,45 @@ def test_hmult_pieces_and_composite_match_oracle(F, eng, logn, L, K, dnum, bits,
         assert (ks.rescale(up(both), 2).download() == R.rescale_ref(both, qs, L, logn, plain_modulus=t_plain)).all()
 
 
+@pytest.mark.parametrize("logn,L,K,dnum,ct_bits,sp_bits", [
+    (13, 4, 2, 2, [50] * 4, [50] * 2),            # FP64 limbs throughout
+    (14, 5, 2, 5, [50] * 5, [50] * 2),            # one-limb digits (SEAL's form), K = 2
+    (13, 3, 2, 3, [61] * 3, [61] * 2),            # integer path throughout
+    (13, 5, 3, 2, [50, 61, 50, 50, 61], [50, 61, 50]),   # mixed: the last limb on the integer path under FP64 limbs
+    (13, 4, 2, 2, [61, 50, 61, 50], [50, 50]),    # mixed: an FP64 last limb under integer-path limbs
+    (15, 2, 2, 1, [50] * 2, [50] * 2),            # L = 2: one limb survives
+])
+def test_hmult_fused_rescale_matches_oracle_and_two_step_form(F, eng, logn, L, K, dnum, ct_bits, sp_bits):
+    """fhe_hmult at the two-launch sizes with K >= 2 runs the mod-down and the rescale behind ONE forward transform
+    (capi_keyswitch.cpp ks_finish_rescale: NTT(conv_j + P y) instead of NTT(conv_j) and NTT(y)).  Its words must be the oracle's
+    multiply -> relinearize -> mod_switch (reliability_test/dotprod_test.cu:113-115) and the engine's own two-step form's."""
+    from oracle import keyswitch_ref as R
+    N = 1 << logn
+    qs = F.create_moduli(N, list(ct_bits) + list(sp_bits))
+    t = eng.tables(logn, qs)
+    rng = np.random.default_rng(logn * 100 + L * 10 + K)
+    a0, a1, b0, b1 = (_limbs(rng, qs[:L], N) for _ in range(4))
+    a0[:, :3] = np.array([[0, 1, q - 1] for q in qs[:L]], dtype=np.uint64)
+    rlk = _key(rng, qs, dnum, N)
+    ks = F.KeySwitch(eng, t, L, K, dnum)
+    up = eng.upload
+    h0, h1 = R.hmult_ref(a0, a1, b0, b1, rlk, qs, L, K, dnum, logn, rescale=True)
+    got = {}
+    try:
+        for fused in (1, 0):
+            eng.set_option("hmult_fused_rescale", fused)
+            o0, o1 = ks.hmult(up(a0), up(a1), up(b0), up(b1), up(rlk), rescale=True)
+            got[fused] = (o0.download(), o1.download())
+    finally:
+        eng.set_option("hmult_fused_rescale", 1)
+    for fused in (1, 0):
+        assert (got[fused][0] == h0).all() and (got[fused][1] == h1).all(), f"fused={fused}"
+    # the un-rescaled form is untouched by the switch
+    o0, o1 = ks.hmult(up(a0), up(a1), up(b0), up(b1), up(rlk), rescale=False)
+    w0, w1 = R.hmult_ref(a0, a1, b0, b1, rlk, qs, L, K, dnum, logn, rescale=False)
+    assert (o0.download() == w0).all() and (o1.download() == w1).all()
+
+
 def _switch_key(O, qs, L, K, dnum, logn, s, s_target, rnd):
     """evk_d = (-a_d s + e_d + P Qhat_d [Qhat_d^-1]_{Q_d} s_target, a_d), NTT domain, (dnum, 2, L+K, N)."""
     N, M = 1 << logn, L + K
