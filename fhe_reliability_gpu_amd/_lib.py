@@ -115,6 +115,9 @@ _SIG = {
     "fhe_relinearize": (ci, [vp, vp, vp, vp, vp, vp, vp, vp, vp]),
     "fhe_rescale": (ci, [vp, vp, vp, vp, sz, vp]),
     "fhe_hmult": (ci, [vp, vp, vp, vp, vp, vp, vp, vp, vp, ci, vp]),
+    "fhe_hmult_shard_fusable": (ci, [vp, vp]),
+    "fhe_hmult_shard_finish_begin": (ci, [vp, vp, vp, vp, vp]),
+    "fhe_hmult_shard_finish_end": (ci, [vp, vp, vp, vp, vp, vp, vp]),
     "fhe_modadd": (ci, [vp, vp, vp, vp, vp, sz, sz, sz, vp]),
     "fhe_modsub": (ci, [vp, vp, vp, vp, vp, sz, sz, sz, vp]),
     "fhe_scalar_affine": (ci, [vp, vp, vp, p64, p64, vp, sz, sz, sz, vp]),

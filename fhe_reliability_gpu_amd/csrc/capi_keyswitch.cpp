@@ -103,15 +103,17 @@ static int ks_create(fhe_ctx *ctx, const fhe_ntt_tables *t, int L, int K, int dn
             if (!pinv[j]) return fail(FHE_ERR_INVALID, "special primes must be coprime to the ciphertext primes");
         }
         HIP_TRY(p->pinv.upload(pinv));
-        if (!sharded) {
-            std::vector<Tw> pq(sh.cn);
-            for (int j = 0; j < sh.cn; j++) {
-                u64 pm = 1 % Q[j];
-                for (u64 pk : P) pm = host::mul_mod(pm, pk % Q[j], Q[j]);
-                pq[j] = t->path[j] == PATH_F64 ? ArithF64::encode(pm, Q[j]) : ArithU64::encode(pm, Q[j]);
-            }
-            HIP_TRY(p->pq_tw.upload(pq));
+    }
+    {
+        // P mod q_j as a twiddle of limb j's arithmetic, indexed by TABLE limb (ColAddSrc::w), every ciphertext limb
+        std::vector<Tw> pq(L);
+        for (int j = 0; j < L; j++) {
+            const u64 qj = t->q[j];
+            u64 pm = 1 % qj;
+            for (int k = 0; k < K; k++) pm = host::mul_mod(pm, t->q[L + k] % qj, qj);
+            pq[j] = t->path[j] == PATH_F64 ? ArithF64::encode(pm, qj) : ArithU64::encode(pm, qj);
         }
+        HIP_TRY(p->pq_tw.upload(pq));
     }
     p->up_trivial = p->alpha == 1 && t->log_n >= 13;
     // every owned limb of every digit's extension except the digit's own limbs, one list per arithmetic path
@@ -422,27 +424,61 @@ static int ks_finish(fhe_ctx *ctx, fhe_keyswitch *p, uint64_t *d_out0, uint64_t 
 // the second factor (RowEpiArgs::scal2).  The full-width transform of the y residues, the L-limb intermediate and its re-read disappear.
 bool ks_rescale_fusable(const fhe_ctx *ctx, const fhe_keyswitch *p)
 {
-    return ctx->hmult_fused_rescale && !p->sharded && !p->plain_modulus && !ctx->trace_on && ks_fast_path(ctx, p) && p->log_n >= 13 && p->K >= 2 && p->L >= 2 && p->rs_n == p->L - 1 &&
+    return ctx->hmult_fused_rescale && !p->plain_modulus && !ctx->trace_on && ks_fast_path(ctx, p) && p->log_n >= 13 && p->K >= 2 && p->L >= 2 && p->rs_bc != nullptr &&
            p->pq_tw.bytes != 0;
 }
 
-static int ks_finish_rescale(fhe_ctx *ctx, fhe_keyswitch *p, uint64_t *d_out0, uint64_t *d_out1, const uint64_t *d_add0, const uint64_t *d_add1, hipStream_t st)
+// the last limb's part of y, INTT(acc P^-1 + d), in place in row L-1 of acc -- for a plan whose special limbs' INTT does not take it along
+// (sharded: that launch writes into the gather buffer)
+static int ks_rescale_last(fhe_ctx *ctx, fhe_keyswitch *p, const uint64_t *d_add0, const uint64_t *d_add1, hipStream_t st)
+{
+    if (!p->own_last) return FHE_OK;
+    const fhe_ntt_tables *t = p->t;
+    const size_t N = (size_t)1 << p->log_n, MO = p->m_own, R = (size_t)p->L - 1, lr = R - p->sh.clo;
+    const LimbParams *lp = t->d_lp.as<LimbParams>();
+    u64 *acc = p->acc_cur();
+    const SubScaleArgs sa{acc + lr * N, acc + (MO + lr) * N, acc + lr * N, nullptr, d_add0 ? d_add0 + lr * N : nullptr, p->pinv.as<u64>() + lr, (u64)(MO * N), 0, lp, (u32)R, 1u, p->log_n,
+                          d_add1 ? d_add1 + lr * N : nullptr};
+    hipError_t e = launch_sub_scale(st, sa);
+    if (e != hipSuccess) return hip_fail(e, "launch_sub_scale");
+    PassArgs a{acc + lr * N, lp, (u32)R, 1u, 2u, (u32)MO};
+    if ((e = launch_ntt(st, a, p->log_n, true, t->path[R], 1)) != hipSuccess) return hip_fail(e, "launch_ntt");
+    return FHE_OK;
+}
+
+// conversion of the (gathered) special limbs to the owned ciphertext limbs; the owner of limb L-1 then forms y (rs_bc: [2][N])
+static int ks_finish_rescale_begin(fhe_ctx *ctx, fhe_keyswitch *p, hipStream_t st)
 {
     const fhe_ntt_tables *t = p->t;
-    const size_t N = (size_t)1 << p->log_n, MO = p->m_own, L = p->L, R = L - 1;
+    const KsShard &sh = p->sh;
+    if (!sh.cn) return FHE_OK;
+    const size_t N = (size_t)1 << p->log_n, MO = p->m_own, R = (size_t)p->L - 1, lr = R - sh.clo;
     const LimbParams *lp = t->d_lp.as<LimbParams>();
     u64 *acc = p->acc_cur(), *conv = p->conv_cur();
     hipError_t e = launch_baseconv_exact_jobs(st, p->down_jobs.as<BcJob>(), 2, p->down->dev.m, p->down->dev.k, p->down->dev.f64 != 0, N,
                                               p->down->dev.m <= 16 ? 1u << (p->down->dev.m - 1) : 0u);
     if (e != hipSuccess) return hip_fail(e, "launch_baseconv_exact_jobs");
-    {
-        // y = INTT(v_{L-1}) = INTT(acc P^-1 + d) - P^-1 conv_{L-1}: the first term sits in row L-1 of acc (ks_special_intt, with_last)
-        const SubScaleArgs sa{p->rs_bc, p->rs_bc + N, nullptr, conv + R * N, acc + R * N, p->pinv.as<u64>() + R, 0, (u64)(L * N), lp, (u32)R, 1u, p->log_n, acc + (MO + R) * N};
+    if (p->own_last) {
+        // y = INTT(v_{L-1}) = INTT(acc P^-1 + d) - P^-1 conv_{L-1}: the first term sits in row L-1 of acc
+        const SubScaleArgs sa{p->rs_bc, p->rs_bc + N, nullptr, conv + lr * N, acc + lr * N, p->pinv.as<u64>() + lr, 0, (u64)((size_t)sh.cn * N), lp, (u32)R, 1u, p->log_n,
+                              acc + (MO + lr) * N};
         if ((e = launch_sub_scale(st, sa)) != hipSuccess) return hip_fail(e, "launch_sub_scale");
     }
+    return FHE_OK;
+}
+
+// ONE forward transform of conv_j + P y on the owned limbs below L-1, its tail ending with q_last^-1; outputs: rs_n rows per part
+static int ks_finish_rescale_end(fhe_ctx *ctx, fhe_keyswitch *p, uint64_t *d_out0, uint64_t *d_out1, const uint64_t *d_add0, const uint64_t *d_add1, hipStream_t st)
+{
+    const fhe_ntt_tables *t = p->t;
+    const KsShard &sh = p->sh;
+    if (!p->rs_n) return FHE_OK;
+    const size_t N = (size_t)1 << p->log_n, MO = p->m_own;
+    const LimbParams *lp = t->d_lp.as<LimbParams>();
+    u64 *acc = p->acc_cur(), *conv = p->conv_cur();
     const ColAddSrc as{p->rs_bc, (u64)N, p->pq_tw.as<Tw>()};
-    return for_each_run(t, R, 0, [&](size_t off, size_t len, int path) -> int {
-        PassArgs a{conv + off * N, lp, (u32)off, (u32)len, (u32)(2 * len), (u32)L};
+    return for_each_run(t, p->rs_n, sh.clo, [&](size_t off, size_t len, int path) -> int {
+        PassArgs a{conv + off * N, lp, (u32)(sh.clo + off), (u32)len, (u32)(2 * len), (u32)sh.cn};
         RowEpiArgs ep{{d_out0 + off * N, d_out1 + off * N, nullptr}, {d_add0 ? d_add0 + off * N : nullptr, d_add1 ? d_add1 + off * N : nullptr, nullptr},
                       acc + off * N, (u64)(MO * N), p->pinv.as<u64>() + off};
         ep.scal2 = p->qlast_inv.as<u64>() + off;
@@ -469,7 +505,10 @@ int keyswitch_core(fhe_ctx *ctx, fhe_keyswitch *p, uint64_t *d_out0, uint64_t *d
     if ((rc = ks_extend_mac(ctx, p, d_c, d_evk, st))) return rc;
     TraceScope tr_ms(ctx, st, "MODSWITCH");
     if ((rc = ks_special_intt(ctx, p, st, 0, rescale, d_add0, d_add1))) return rc;
-    if (rescale) return ks_finish_rescale(ctx, p, d_out0, d_out1, d_add0, d_add1, st);
+    if (rescale) {
+        if ((rc = ks_finish_rescale_begin(ctx, p, st))) return rc;
+        return ks_finish_rescale_end(ctx, p, d_out0, d_out1, d_add0, d_add1, st);
+    }
     return ks_finish(ctx, p, d_out0, d_out1, d_add0, d_add1, st);
 }
 
@@ -586,6 +625,37 @@ int fhe_keyswitch_shard_finish(fhe_ctx *ctx, fhe_keyswitch *p, uint64_t *d_out0_
     if (!ctx || !p || ((!d_out0_local || !d_out1_local) && p->sh.cn)) return fail(FHE_ERR_INVALID, "null argument");
     HIP_TRY(hipSetDevice(ctx->device));
     return ks_finish(ctx, p, d_out0_local, d_out1_local, d_add0_local, d_add1_local, pick(ctx, stream));
+}
+
+// Sharded hmult with the mod-down and the rescale behind one transform (ks_finish_rescale_*): after the second all-gather
+//   fhe_hmult_shard_finish_begin  (owner of limb L-1: y into the broadcast buffer)  ->  ONE broadcast of 2 x N words  ->
+//   fhe_hmult_shard_finish_end    (the owned limbs below L-1 of both parts, rs_n rows each)
+// instead of fhe_keyswitch_shard_finish + fhe_rescale_shard_begin / _finish: same words, same three collectives per hmult.
+int fhe_hmult_shard_fusable(const fhe_ctx *ctx, const fhe_keyswitch *p)
+{
+    return ctx && p && p->sharded && ks_rescale_fusable(ctx, p) ? 1 : 0;
+}
+
+int fhe_hmult_shard_finish_begin(fhe_ctx *ctx, fhe_keyswitch *p, const uint64_t *d_add0_local, const uint64_t *d_add1_local, void *stream)
+{
+    if (!ctx || !p) return fail(FHE_ERR_INVALID, "null argument");
+    if (!p->sharded || !ks_rescale_fusable(ctx, p)) return fail(FHE_ERR_UNSUPPORTED, "this plan rescales in a separate step (fhe_hmult_shard_fusable)");
+    HIP_TRY(hipSetDevice(ctx->device));
+    hipStream_t st = pick(ctx, stream);
+    int rc;
+    if ((rc = ks_rescale_last(ctx, p, d_add0_local, d_add1_local, st))) return rc;
+    return ks_finish_rescale_begin(ctx, p, st);
+}
+
+int fhe_hmult_shard_finish_end(fhe_ctx *ctx, fhe_keyswitch *p, uint64_t *d_out0_local, uint64_t *d_out1_local, const uint64_t *d_add0_local,
+                               const uint64_t *d_add1_local, void *stream)
+{
+    if (!ctx || !p) return fail(FHE_ERR_INVALID, "null argument");
+    if (!p->sharded || !ks_rescale_fusable(ctx, p)) return fail(FHE_ERR_UNSUPPORTED, "this plan rescales in a separate step (fhe_hmult_shard_fusable)");
+    if (p->rs_n && (!d_out0_local || !d_out1_local)) return fail(FHE_ERR_INVALID, "null argument");
+    if (p->rs_n && d_out0_local == d_out1_local) return fail(FHE_ERR_INVALID, "the two output parts must be distinct buffers");
+    HIP_TRY(hipSetDevice(ctx->device));
+    return ks_finish_rescale_end(ctx, p, d_out0_local, d_out1_local, d_add0_local, d_add1_local, pick(ctx, stream));
 }
 
 // the last phase of a rotation: the mod-down with sigma(c0) added to the first part -- through the Galois map on the fused tail's

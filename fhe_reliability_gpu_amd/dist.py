@@ -300,6 +300,24 @@ class ShardedKeySwitch:
         check(lib.fhe_rescale_shard_finish(self.eng._h, self._h, self._p(out), self._p(parts_local), parts_local.shape[0], self._stream()))
         return out
 
+    # hmult with the mod-down and the rescale behind one forward transform (fhe_hmult_shard_finish_*): after the second all-gather
+    @property
+    def fused_rescale(self) -> bool:
+        from ._lib import lib
+        return bool(lib.fhe_hmult_shard_fusable(self.eng._h, self._h))
+
+    def hm_finish_begin(self, add0, add1):
+        from ._lib import check, lib
+        check(lib.fhe_hmult_shard_finish_begin(self.eng._h, self._h, self._p(add0), self._p(add1), self._stream()))
+
+    def hm_finish_end(self, add0, add1):
+        import torch
+
+        from ._lib import check, lib
+        out = torch.empty((2, self.rs_rows, self.t.N), dtype=torch.int64, device=self.g1.device)
+        check(lib.fhe_hmult_shard_finish_end(self.eng._h, self._h, self._p(out[0]), self._p(out[1]), self._p(add0), self._p(add1), self._stream()))
+        return out
+
     def close(self):
         from ._lib import lib
         if getattr(self, "_h", None) and self.eng._h:
@@ -435,6 +453,37 @@ def sharded_hmult(plan, a0, a1, b0, b1, rlk_local, rescale: bool = True, timings
     import torch
     with (plan.stream_scope() if hasattr(plan, "stream_scope") else contextlib.nullcontext()):
         d0, d1, d2 = plan.tensor(a0, a1, b0, b1)
+        if rescale and getattr(plan, "fused_rescale", False):
+            # the mod-down and the rescale share one forward transform: the broadcast (y = the last limbs after the mod-down, in
+            # coefficient form) sits between the conversion and that transform; same three collectives
+            ev = None
+            if timings is not None:
+                ev = [torch.cuda.Event(enable_timing=True) for _ in range(8)]
+                ev[0].record()
+            plan.begin(d2)
+            if ev:
+                ev[1].record()
+            all_gather_slots(plan.g1, plan.rows1, plan.group)
+            if ev:
+                ev[2].record()
+            plan.inner(d2, rlk_local)
+            if ev:
+                ev[3].record()
+            all_gather_slots(plan.g2, plan.rows2, plan.group)
+            if ev:
+                ev[4].record()
+            plan.hm_finish_begin(d0, d1)
+            if ev:
+                ev[5].record()
+            broadcast_rows(plan.bc[:2], plan.last_owner, plan.group)
+            if ev:
+                ev[6].record()
+            r = plan.hm_finish_end(d0, d1)
+            if ev:
+                ev[7].record()
+                timings.setdefault("events", []).append(ev[:6])
+                timings.setdefault("rescale_events", []).append([ev[4], ev[5], ev[6], ev[7]])
+            return r[0], r[1]
         c0, c1 = sharded_keyswitch(plan, d2, rlk_local, add0=d0, add1=d1, timings=timings)
         if not rescale:
             return c0, c1

@@ -348,6 +348,18 @@ int fhe_rescale_shard_finish(fhe_ctx *ctx, fhe_keyswitch *p, uint64_t *d_out_loc
  * transforms / products, may run on different streams concurrently. */
 int fhe_hmult(fhe_ctx *ctx, fhe_keyswitch *p, uint64_t *d_out0, uint64_t *d_out1, const uint64_t *d_a0, const uint64_t *d_a1,
               const uint64_t *d_b0, const uint64_t *d_b1, const uint64_t *d_relin_key, int rescale, void *stream);
+/* multiply -> relinearize -> mod_switch with the limbs sharded, the mod-down and the rescale behind ONE forward transform (what
+ * fhe_hmult does on one device where fhe_hmult_shard_fusable() / the shape allow: two-launch sizes, K >= 2, CKKS form): after
+ * fhe_tensor_product, fhe_keyswitch_shard_begin / _inner and their two all-gathers,
+ *   _finish_begin: converts the gathered special limbs to this rank's rows; the owner of limb L-1 writes
+ *                  y = INTT(v_{L-1}) of both parts into d_bcast ([2][N] of it), d_add*_local = this rank's rows of d0 / d1;
+ *   the host broadcasts d_bcast from that rank (the one exchange of the rescale);
+ *   _finish_end:   d_out*_local = [out_rows][N] (fhe_rescale_shard_info), the owned limbs below L-1 of the rescaled parts.
+ * Same words as fhe_keyswitch_shard_finish + fhe_rescale_shard_begin / _finish (reliability_test/dotprod_test.cu:114-115). */
+int fhe_hmult_shard_fusable(const fhe_ctx *ctx, const fhe_keyswitch *p);
+int fhe_hmult_shard_finish_begin(fhe_ctx *ctx, fhe_keyswitch *p, const uint64_t *d_add0_local, const uint64_t *d_add1_local, void *stream);
+int fhe_hmult_shard_finish_end(fhe_ctx *ctx, fhe_keyswitch *p, uint64_t *d_out0_local, uint64_t *d_out1_local, const uint64_t *d_add0_local,
+                               const uint64_t *d_add1_local, void *stream);
 
 /* Operation trace in the line format the reference's tools consume
  * (profile_framewk/build/analyze_trace.py:16-19, sum_trace.py:16-19): "frontend: ROTATE",

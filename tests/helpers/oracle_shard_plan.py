@@ -190,3 +190,18 @@ class OracleShardPlan:
                 out[p, j] = self._t(O.modmul(diff, np.full(N, pow(ql % q, -1, q), dtype=np.uint64), q))
         return out
 
+
+    # ---- hmult with the broadcast between the conversion and the last transform (dist.sharded_hmult's fused flow,
+    # fhe_hmult_shard_finish_begin / _end): stated here with the plain formulas -- mod-down of the owned rows, the owner's last limb
+    # to coefficient form for the broadcast, then the rescale of the rows below it -- the protocol (who holds what when) is what the
+    # gloo tests exercise; the engine's one-transform arithmetic is checked against these words on the GPU
+    fused_rescale = True
+
+    def hm_finish_begin(self, add0, add1):
+        import torch
+        c0, c1 = self.finish(add0, add1)
+        self._hm_parts = torch.stack([c0, c1])
+        self.rescale_begin(self._hm_parts[:, :, :])
+
+    def hm_finish_end(self, add0, add1):
+        return self.rescale_finish(self._hm_parts)

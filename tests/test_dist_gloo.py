@@ -161,7 +161,7 @@ def test_sharded_rotate_hoisted_gloo(tmp_path, world, L, K, dnum):
         assert (np.concatenate([g[2 * r] for g in got], axis=0) == w0).all() and (np.concatenate([g[2 * r + 1] for g in got], axis=0) == w1).all(), e
 
 
-def _hm_worker(rank, world, port, logn, L, K, dnum, out_dir):
+def _hm_worker(rank, world, port, logn, L, K, dnum, out_dir, fused=True):
     import torch
     import torch.distributed as dist
 
@@ -179,21 +179,23 @@ def _hm_worker(rank, world, port, logn, L, K, dnum, out_dir):
         to_t = lambda a: torch.from_numpy(np.ascontiguousarray(a).view(np.int64).copy())
         rows = own_ct_rows(lay)
         plan = OracleShardPlan(qs, logn, L, K, dnum)
+        plan.fused_rescale = fused       # True: the broadcast sits between the conversion and the last transform (hm_finish_begin / _end)
         o0, o1 = sharded_hmult(plan, to_t(a0[rows]), to_t(a1[rows]), to_t(b0[rows]), to_t(b1[rows]), to_t(rlk[:, :, own_rows(lay)]))
         np.save(os.path.join(out_dir, f"hm{rank}.npy"), np.stack([o0.numpy().view(np.uint64), o1.numpy().view(np.uint64)]))
     finally:
         dist.destroy_process_group()
 
 
-@pytest.mark.parametrize("world,L,K,dnum", [(2, 4, 2, 2), (3, 5, 2, 3), (3, 3, 1, 3)])
-def test_sharded_hmult_gloo(tmp_path, world, L, K, dnum):
+@pytest.mark.parametrize("world,L,K,dnum,fused", [(2, 4, 2, 2, True), (3, 5, 2, 3, True), (3, 3, 1, 3, True), (2, 4, 2, 2, False), (3, 5, 2, 3, False)])
+def test_sharded_hmult_gloo(tmp_path, world, L, K, dnum, fused):
     """BASELINE config 4's composite with the limbs sharded: tensor product on the owned rows, the sharded key switch with d0 / d1 as
-    addends, the rescale with ONE broadcast of the last limbs -- concatenated per-rank results equal oracle hmult_ref."""
+    addends, the rescale with ONE broadcast of the last limbs -- concatenated per-rank results equal oracle hmult_ref.  Both flows of
+    dist.sharded_hmult: the broadcast after the key switch's finish (separate rescale) and between its conversion and last transform."""
     import torch.multiprocessing as mp
     from oracle.keyswitch_ref import hmult_ref
 
     logn = 6
-    mp.spawn(_hm_worker, args=(world, _free_port(), logn, L, K, dnum, str(tmp_path)), nprocs=world, join=True)
+    mp.spawn(_hm_worker, args=(world, _free_port(), logn, L, K, dnum, str(tmp_path), fused), nprocs=world, join=True)
     qs, a0, rlk, a1 = _ks_case(logn, L, K, dnum)
     _, b0, _, b1 = _ks_case(logn, L, K, dnum + 7)
     qcol = np.array(qs[:L], dtype=np.uint64)[:, None]

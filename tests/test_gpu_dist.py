@@ -148,6 +148,15 @@ def _gloo_gpu_hmult_worker(rank, world, port, logn, L, K, dnum, bits, out_dir):
         rows = own_ct_rows(lay)
         plan = ShardedKeySwitch(eng, t, L, K, dnum)
         o0, o1 = sharded_hmult(plan, _to_cuda(a0[rows]), _to_cuda(a1[rows]), _to_cuda(b0[rows]), _to_cuda(b1[rows]), _to_cuda(rlk[:, :, own_rows(lay)]))
+        # where the shape allows, that ran fhe_hmult_shard_finish_begin / _end (one transform for the mod-down and the rescale); the
+        # separate key-switch finish + rescale must give the same words
+        fused = plan.fused_rescale
+        assert fused == (logn >= 13 and K >= 2)
+        eng.set_option("hmult_fused_rescale", 0)
+        assert not plan.fused_rescale
+        p0, p1 = sharded_hmult(plan, _to_cuda(a0[rows]), _to_cuda(a1[rows]), _to_cuda(b0[rows]), _to_cuda(b1[rows]), _to_cuda(rlk[:, :, own_rows(lay)]))
+        eng.set_option("hmult_fused_rescale", 1)
+        assert torch.equal(o0, p0) and torch.equal(o1, p1)
         # the BGV form of the rescale on the same plan: the owner of the last limb broadcasts t [c t^-1]_q_last's source limb
         plan.set_plain_modulus(786433)
         rb = sharded_rescale(plan, torch.stack([_to_cuda(a0[rows]), _to_cuda(a1[rows])]))
@@ -158,7 +167,7 @@ def _gloo_gpu_hmult_worker(rank, world, port, logn, L, K, dnum, bits, out_dir):
         dist.destroy_process_group()
 
 
-@pytest.mark.parametrize("world,logn,L,K,dnum,bits", [(1, 13, 5, 2, 3, 50), (2, 12, 6, 2, 3, 50), (3, 13, 7, 3, 2, 61), (2, 14, 4, 1, 4, 50)])
+@pytest.mark.parametrize("world,logn,L,K,dnum,bits", [(1, 13, 5, 2, 3, 50), (2, 12, 6, 2, 3, 50), (3, 13, 7, 3, 2, 61), (2, 14, 4, 1, 4, 50), (2, 13, 4, 2, 2, 50)])
 def test_sharded_hmult_real_plan(tmp_path, world, logn, L, K, dnum, bits):
     """BASELINE config 4's composite with the limbs sharded, on the real C-ABI plan (ranks share cuda:0, joins over gloo): tensor
     product on the owned rows, sharded relinearisation (d0 / d1 as addends of its last launch), sharded rescale (the last limb's owner
