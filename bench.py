@@ -89,10 +89,20 @@ def traffic_floor_us(kind, logn, L, K, dnum):
     sweeps += L + ext                               # digit extension: reads the input, writes the extended limbs
     sweeps += (2 * ext if two == 2 else 0)          # column pass of the extended limbs
     sweeps += ext + L + 2 * dnum * M + 2 * M        # row pass + inner product
+    addends = L if kind == "rotate" else 2 * L if kind == "hmult" else 0
+    if kind == "hmult" and two == 2 and K >= 2:
+        # fhe_hmult's own launch list at these shapes: the mod-down and the rescale share one forward transform (capi_keyswitch.cpp
+        # ks_finish_rescale_*): the last limb rides along with the special limbs' INTT, y costs two word-wise launches of a few limbs
+        R = L - 1
+        sweeps += 6 + 2 * two * 2 * (K + 1)         # acc P^-1 + d on the last limb; INTT of the special limbs and of that limb
+        sweeps += 2 * K + 2 * L + 6                 # mod-down conversion; y
+        sweeps += 2 * 2 * R + 2                     # column pass of the converted limbs (+ y)
+        sweeps += 2 * R + 2 * R + 2 * R + 2 * R     # row pass with the tail (converted limbs, sums, addends, result)
+        sweeps += 7 * L                             # tensor product: four operands in, three parts out
+        return sweeps * (8 << logn) / (FABRIC_SUSTAINED_GBS * 1e9) * 1e6
     sweeps += 2 * two * 2 * K                       # INTT of the special limbs, both halves
     sweeps += 2 * K + 2 * L                         # mod-down conversion
     sweeps += (2 * 2 * L if two == 2 else 0)        # column pass of the converted limbs
-    addends = L if kind == "rotate" else 2 * L if kind == "hmult" else 0
     sweeps += 2 * L + 2 * L + addends + 2 * L       # row pass with the tail
     if kind == "rotate":
         sweeps += L                                 # sigma(c1) kept for the inner product
