@@ -141,6 +141,111 @@ FHE_D void radix_inv(typename A::elem (&x)[1 << K], TwPtr tw, int s, u32 prefix,
     }
 }
 
+// ---------------------------------------------------------------------------
+// Inverse passes of ArithF64 with the lazy range tracked PER REGISTER (RED = INV_LAZY | entry bound in eighths of q).
+// A Gentleman-Sande stage maps bounds (bX, bY) (units of q) to (bX + bY, 0.5 + (bX + bY)/4): only a register that keeps taking the SUM
+// branch grows, every product output starts again near q/2.  Which branch a register takes at each stage of a register step is
+// known at compile time, so instead of folding all 2^K registers back every second or third stage (reduce_mask above) the plan below
+// folds exactly the registers whose pair would exceed 8q < 2^53 (every sum, difference and product input stays an exact integer
+// in a double: tests/ + the derivation in DESIGN.md "lazy FP64 ranges"), and at the end of a step those above 2q -- a thread of the NEXT
+// step holds values from one register index of this step, unknown at compile time there, so steps hand over under a common bound.
+// 2^16: 2.7 folds per point instead of 5.
+// ---------------------------------------------------------------------------
+constexpr u32 INV_LAZY = 0x80000000u;
+constexpr int INV_LAZY_LIMIT8 = 64;        // 8 q
+constexpr int INV_LAZY_EXIT8 = 16;         // 2 q: bound under which a step hands its registers over
+template <int K> struct InvLazyPlan {
+    u32 before[K];      // bit r: fold register r before executed stage v
+    u32 at_exit;        // bit r: fold register r after the last stage
+    int out8;           // bound of every register afterwards, eighths of q, rounded up
+};
+// bounds are kept in 1/1024 q, rounded up at every operation (a fold leaves |x| <= q/2 + an ulp of the quotient: 513/1024;
+// a product 0.5 + (bX + bY)/4 + the same slack)
+template <int K> FHE_HD constexpr InvLazyPlan<K> inv_lazy_plan(int in8, int exit8, bool fold_last)
+{
+    constexpr int R = 1 << K;
+    InvLazyPlan<K> p{};
+    int b[R] = {};
+    for (int r = 0; r < R; r++) b[r] = in8 * 128;
+    const int limit = INV_LAZY_LIMIT8 * 128, folded = 513;
+    for (int v = 0; v < K; v++) {
+        const int u = K - 1 - v, half = R >> (u + 1);
+        u32 m = 0;
+        for (int blk = 0; blk < (1 << u); blk++)
+            for (int j = 0; j < half; j++) {
+                const int i0 = blk * 2 * half + j, i1 = i0 + half;
+                if (b[i0] + b[i1] > limit) {
+                    const int big = b[i0] >= b[i1] ? i0 : i1;
+                    b[big] = folded;
+                    m |= 1u << big;
+                    if (b[i0] + b[i1] > limit) {
+                        const int other = big == i0 ? i1 : i0;
+                        b[other] = folded;
+                        m |= 1u << other;
+                    }
+                }
+                const int sum = b[i0] + b[i1], prod = 513 + (sum + 3) / 4;
+                b[i0] = (fold_last && u == 0) ? prod : sum;
+                b[i1] = prod;
+            }
+        p.before[v] = m;
+    }
+    int mx = 0;
+    for (int r = 0; r < R; r++) {
+        if (b[r] > exit8 * 128) {
+            b[r] = folded;
+            p.at_exit |= 1u << r;
+        }
+        mx = b[r] > mx ? b[r] : mx;
+    }
+    p.out8 = (mx + 127) / 128;
+    return p;
+}
+// entry bound of executed step `se` of an inverse pass whose first step starts from in8 (ST = the pass's Steps; the inverse runs them last to first)
+template <class ST> FHE_HD constexpr int inv_lazy_step_in8(int in8, int se)
+{
+    int b = in8;
+    for (int i = 0; i < se; i++) {
+        const int k = ST::k(ST::NSTEP - 1 - i);
+        b = k == 1 ? inv_lazy_plan<1>(b, INV_LAZY_EXIT8, false).out8 : k == 2 ? inv_lazy_plan<2>(b, INV_LAZY_EXIT8, false).out8
+          : k == 3 ? inv_lazy_plan<3>(b, INV_LAZY_EXIT8, false).out8 : k == 4 ? inv_lazy_plan<4>(b, INV_LAZY_EXIT8, false).out8
+                                                                             : inv_lazy_plan<5>(b, INV_LAZY_EXIT8, false).out8;
+    }
+    return b;
+}
+// bound a pass that hands lazy words to the next launch leaves behind
+template <class ST> FHE_HD constexpr int inv_lazy_pass_out8(int in8) { return inv_lazy_step_in8<ST>(in8, ST::NSTEP); }
+
+template <class A, int K, int SBLK, bool FOLD, int IN8, int EXIT8>
+FHE_D void radix_inv_lazy(typename A::elem (&x)[1 << K], TwPtr tw, int s, u32 prefix, const typename A::Ctx &c, const Tw *inv_n)
+{
+    constexpr int R = 1 << K;
+    constexpr InvLazyPlan<K> plan = inv_lazy_plan<K>(IN8, EXIT8, FOLD);
+#pragma unroll
+    for (int v = 0; v < K; v++) {
+        const int u = K - 1 - v;
+#pragma unroll
+        for (int r = 0; r < R; r++)
+            if ((plan.before[v] >> r) & 1) A::reduce(x[r], c);
+        const int half = R >> (u + 1);
+        if (FOLD && u == 0) {
+            const Tw wn = tw[0];
+#pragma unroll
+            for (int j = 0; j < half; j++) A::bfly_inv_scaled(x[j], x[j + half], *inv_n, wn, c);
+            continue;
+        }
+#pragma unroll
+        for (int b = 0; b < (1 << u); b++) {
+            const Tw w = tw[tw_index(SBLK, s + u, (prefix << u) + b)];
+#pragma unroll
+            for (int j = 0; j < half; j++) A::bfly_inv(x[b * 2 * half + j], x[b * 2 * half + j + half], w, c);
+        }
+    }
+#pragma unroll
+    for (int r = 0; r < R; r++)
+        if ((plan.at_exit >> r) & 1) A::reduce(x[r], c);
+}
+
 // Plan of one pass: P stages split into up to three register steps.
 template <int K0_, int K1_, int K2_>
 struct Steps {
