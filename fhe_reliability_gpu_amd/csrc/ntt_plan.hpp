@@ -117,10 +117,15 @@ template <class A, int LOGN, bool INVERSE, int GEO = 0>
 struct Passes {
     typedef PlanGeom<LOGN, GEO> G;
     typedef typename G::PL PL;
-    static constexpr u32 RED_FIRST = INVERSE ? reduce_mask(0, G::PR, A::INV_FIRST, A::INV_NEXT)
-                                             : reduce_mask(0, G::TWO_PASS ? G::PC : G::PR, A::FWD_FIRST, A::FWD_NEXT);
-    static constexpr u32 RED_SECOND = INVERSE ? reduce_mask(G::PR, G::PC, A::INV_FIRST, A::INV_NEXT)
-                                              : reduce_mask(G::PC, G::PR, A::FWD_FIRST, A::FWD_NEXT);
+    // inverse transforms of the FP64 path: lazy range tracked per register (ntt_core.hpp INV_LAZY): the first launch starts from canonical
+    // words (bound q; the fused product's inverse from |.| < 0.6 q), the second from whatever the first one's last step hands over
+    static constexpr bool LAZY_INV = INVERSE && A::PATH == PATH_F64;
+    static constexpr u32 RED_FIRST = LAZY_INV ? (INV_LAZY | 8u)
+                                     : INVERSE ? reduce_mask(0, G::PR, A::INV_FIRST, A::INV_NEXT)
+                                               : reduce_mask(0, G::TWO_PASS ? G::PC : G::PR, A::FWD_FIRST, A::FWD_NEXT);
+    static constexpr u32 RED_SECOND = LAZY_INV ? (INV_LAZY | (u32)inv_lazy_pass_out8<typename PL::Row>(8))
+                                      : INVERSE ? reduce_mask(G::PR, G::PC, A::INV_FIRST, A::INV_NEXT)
+                                                : reduce_mask(G::PC, G::PR, A::FWD_FIRST, A::FWD_NEXT);
     // single pass
     static constexpr int SB = BlkStage<LOGN>::value;
     typedef RowPass<A, typename PL::Row, LOGN, 1, NTT_THREADS, INVERSE, IO_CANONICAL, IO_CANONICAL, RED_FIRST, SB> Single;

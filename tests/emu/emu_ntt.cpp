@@ -293,3 +293,31 @@ extern "C" int emu_ntt(u64 *data, int logn, int inverse, int n_poly, int limbs, 
 }
 
 extern "C" double emu_max_ratio() { return g_max_ratio; }
+
+// the per-register lazy-range plan of K inverse stages (ntt_core.hpp inv_lazy_plan), as the kernels' templates evaluate it
+template <int K> static void dump_plan(int in8, int exit8, int fold, uint32_t *before, uint32_t *at_exit, int *out8)
+{
+    const InvLazyPlan<K> p = inv_lazy_plan<K>(in8, exit8, fold != 0);
+    for (int v = 0; v < K; v++) before[v] = p.before[v];
+    *at_exit = p.at_exit;
+    *out8 = p.out8;
+}
+extern "C" int emu_inv_lazy_plan(int K, int in8, int exit8, int fold, uint32_t *before, uint32_t *at_exit, int *out8)
+{
+    switch (K) {
+    case 1: dump_plan<1>(in8, exit8, fold, before, at_exit, out8); return 0;
+    case 2: dump_plan<2>(in8, exit8, fold, before, at_exit, out8); return 0;
+    case 3: dump_plan<3>(in8, exit8, fold, before, at_exit, out8); return 0;
+    case 4: dump_plan<4>(in8, exit8, fold, before, at_exit, out8); return 0;
+    case 5: dump_plan<5>(in8, exit8, fold, before, at_exit, out8); return 0;
+    default: return 1;
+    }
+}
+// entry bound of the second launch of a two-launch inverse and of every step, as Passes<> derives them (2^16: Steps<4,4> twice)
+extern "C" int emu_inv_lazy_chain(int k0, int k1, int k2, int in8, int se)
+{
+    if (k2) return k1 == 3 ? inv_lazy_step_in8<Steps<3, 3, 3>>(in8, se) : inv_lazy_step_in8<Steps<4, 4, 4>>(in8, se);
+    if (k0 == 4 && k1 == 4) return inv_lazy_step_in8<Steps<4, 4, 0>>(in8, se);
+    if (k0 == 4 && k1 == 3) return inv_lazy_step_in8<Steps<4, 3, 0>>(in8, se);
+    return -1;
+}

@@ -165,3 +165,68 @@ def test_packed_handoff_forward(emu, bits):
     for p in range(n_poly):
         for l in range(limbs):
             assert (fwd[p, l] == O.nwt_forward(data[p, l], qs[l], rps[l])).all()
+
+
+def test_inverse_lazy_range_plan_is_sound(emu):
+    """The per-register lazy-range plan of the FP64 inverse passes (ntt_core.hpp inv_lazy_plan, evaluated by the kernels' templates at
+    compile time): an independent restatement with exact fractions follows the plan's fold masks and checks that no butterfly ever sees
+    |X| + |Y| above 8 q (q < 2^50: every sum, difference and product input below 2^53, an exact integer in a double), that the registers
+    a step hands over are within the bound it declares, and that the bounds chain through the steps of a pass as Passes<> assumes.
+    Model of one Gentleman-Sande stage: (bX, bY) -> (bX + bY, 1/2 + (bX + bY) / 4 + slack); a fold leaves 1/2 + slack
+    (ArithF64::mulmod / reduce, modarith.hpp)."""
+    from fractions import Fraction as Fr
+    u32p = C.POINTER(C.c_uint32)
+    emu.emu_inv_lazy_plan.restype = C.c_int
+    emu.emu_inv_lazy_plan.argtypes = [C.c_int, C.c_int, C.c_int, C.c_int, u32p, u32p, C.POINTER(C.c_int)]
+    slack = Fr(1, 1 << 40)
+    fewest = {}
+    for K in range(1, 6):
+        R = 1 << K
+        for in8 in (4, 5, 8, 9, 12, 16, 17, 24, 32, 64):
+            for exit8 in (16, 64):
+                for fold in (0, 1):
+                    before = (C.c_uint32 * K)()
+                    at_exit, out8 = C.c_uint32(), C.c_int()
+                    assert emu.emu_inv_lazy_plan(K, in8, exit8, fold, before, C.byref(at_exit), C.byref(out8)) == 0
+                    b = [Fr(in8, 8)] * R
+                    folds = 0
+                    for v in range(K):
+                        u = K - 1 - v
+                        half = R >> (u + 1)
+                        for r in range(R):
+                            if (before[v] >> r) & 1:
+                                b[r] = Fr(1, 2) + slack
+                                folds += 1
+                        for blk in range(1 << u):
+                            for j in range(half):
+                                i0 = blk * 2 * half + j
+                                i1 = i0 + half
+                                ssum = b[i0] + b[i1]
+                                assert ssum <= 8, (K, in8, exit8, fold, v, i0, i1, float(ssum))
+                                prod = Fr(1, 2) + ssum / 4 + slack
+                                b[i0] = prod if (fold and u == 0) else ssum
+                                b[i1] = prod
+                    for r in range(R):
+                        if (at_exit.value >> r) & 1:
+                            b[r] = Fr(1, 2) + slack
+                            folds += 1
+                    assert max(b) <= Fr(out8.value, 8), (K, in8, exit8, fold, float(max(b)), out8.value)
+                    assert max(b) <= max(Fr(exit8, 8), Fr(out8.value, 8)) and (exit8 == 64 or out8.value <= max(exit8, 8) or fold)
+                    fewest[(K, in8, exit8, fold)] = Fr(folds, R)
+    # the point of it: N = 2^16 (Steps<4,4> twice) folds fewer than 3 registers per point where the uniform schedule folds 5
+    emu.emu_inv_lazy_chain.restype = C.c_int
+    chain = [8]
+    for se in (1, 2):
+        chain.append(emu.emu_inv_lazy_chain(4, 4, 0, 8, se))
+    assert chain[1] <= 16 and chain[2] <= 16
+    second = [chain[2], emu.emu_inv_lazy_chain(4, 4, 0, chain[2], 1)]
+    total = Fr(0)
+    for in8, (exit8, fold) in zip([chain[0], chain[1]] + second, [(16, 0), (16, 0), (16, 0), (64, 1)]):
+        key = (4, in8, exit8, fold)
+        if key not in fewest:          # bounds off the sampled grid: count through the plan again
+            before = (C.c_uint32 * 4)()
+            at_exit, out8 = C.c_uint32(), C.c_int()
+            emu.emu_inv_lazy_plan(4, in8, exit8, fold, before, C.byref(at_exit), C.byref(out8))
+            fewest[key] = Fr(sum(bin(m).count("1") for m in before) + bin(at_exit.value).count("1"), 16)
+        total += fewest[key]
+    assert total < 3, float(total)
