@@ -236,6 +236,17 @@ static bool ks_use_fused(const fhe_ctx *ctx, const fhe_keyswitch *p)
     return want && ks_rowmac_supported(p->log_n) && ctx->fault_idx < 0;
 }
 
+// Hoisted rotations share the extended digits: with two or more Galois elements the digits' row passes run ONCE (plain forward
+// transform of the extensions) and every element costs a word-wise inner product that streams digits and key at the fabric's rate,
+// instead of the fused launch repeating all row passes per element (config 5, eight elements: 201 -> 175 us per rotation).  A batch of
+// one, and an explicit ks_fused setting, keep ks_use_fused()'s choice; the sharded phases do not know the batch size and take the
+// shared-row-pass form.
+static bool ks_hoist_fused(const fhe_ctx *ctx, const fhe_keyswitch *p, size_t n_rot)
+{
+    if (ctx->ks_fused < 0 && n_rot != 1) return false;
+    return ks_use_fused(ctx, p);
+}
+
 // the digits' extensions and the part of their forward transform that does not ride on the inner product (everything a hoisted
 // rotation shares between its Galois elements)
 static int ks_extend(fhe_ctx *ctx, fhe_keyswitch *p, hipStream_t st, bool fused)
@@ -765,7 +776,7 @@ extern "C" int fhe_rotate_hoisted(fhe_ctx *ctx, fhe_keyswitch *p, uint64_t *cons
     const fhe_ntt_tables *t = p->t;
     const size_t N = (size_t)1 << p->log_n, MO = p->m_own, L = p->L, K = p->K;
     const LimbParams *lp = t->d_lp.as<LimbParams>();
-    const bool fused = ks_use_fused(ctx, p);
+    const bool fused = ks_hoist_fused(ctx, p, n_rot);
     // shared: decomposition of c1 (no automorphism yet)
     {
         TraceScope tr(ctx, st, "HOIST");
@@ -840,7 +851,7 @@ extern "C" int fhe_rotate_hoisted_shard_extend(fhe_ctx *ctx, fhe_keyswitch *p, v
     if (!p->sharded) return fail(FHE_ERR_INVALID, "a plan without gather buffers runs fhe_rotate_hoisted");
     if (p->log_n < 5 || !ks_fast_path(ctx, p)) return fail(FHE_ERR_UNSUPPORTED, "hoisted rotations need N >= 2^5 and the default transform path");
     HIP_TRY(hipSetDevice(ctx->device));
-    return ks_extend(ctx, p, pick(ctx, stream), ks_use_fused(ctx, p));
+    return ks_extend(ctx, p, pick(ctx, stream), ks_hoist_fused(ctx, p, 0));
 }
 
 extern "C" int fhe_rotate_hoisted_shard_inner(fhe_ctx *ctx, fhe_keyswitch *p, const uint64_t *d_c1_local, const uint64_t *d_prepared_key_local,
@@ -850,7 +861,7 @@ extern "C" int fhe_rotate_hoisted_shard_inner(fhe_ctx *ctx, fhe_keyswitch *p, co
     if (!p->sharded) return fail(FHE_ERR_INVALID, "a plan without gather buffers runs fhe_rotate_hoisted");
     HIP_TRY(hipSetDevice(ctx->device));
     hipStream_t st = pick(ctx, stream);
-    int rc = ks_mac(ctx, p, d_c1_local, d_prepared_key_local, st, ks_use_fused(ctx, p));
+    int rc = ks_mac(ctx, p, d_c1_local, d_prepared_key_local, st, ks_hoist_fused(ctx, p, 0));
     return rc ? rc : ks_special_intt(ctx, p, st, galois_elt);
 }
 
