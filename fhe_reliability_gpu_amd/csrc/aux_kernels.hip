@@ -183,6 +183,45 @@ hipError_t launch_bitrev_scale(hipStream_t st, u64 *dst, const u64 *src, int log
 }
 
 // ---------------------------------------------------------------------------
+// dst[v][c][r] = src[v][r][c] (* w^(r c) mod q): the transposes of the four-step flow for N past the largest single plan
+// (reliability_test/four_step_ntt_prot.py:81, 93, 105-108), 32 x 32 tiles through LDS so that both sides move whole 256-byte
+// segments.  w^(r c) from two tables: w^e = tlo[e & (2^lo_bits - 1)] * thi[e >> lo_bits].
+// ---------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void k_transpose_tw(u64 *dst, const u64 *src, u32 rows, u32 cols, ModConst mc, const u64 *tlo, const u64 *thi, int lo_bits)
+{
+    __shared__ u64 tile[32][33];
+    const u64 q = mc.q, r0 = mc.r0, r1 = mc.r1;
+    const size_t vec = (size_t)blockIdx.z * rows * cols;
+    const u32 c0 = blockIdx.x * 32, rr0 = blockIdx.y * 32, tx = threadIdx.x & 31, ty = threadIdx.x >> 5;
+    for (u32 k = ty; k < 32; k += 8) {
+        const u32 r = rr0 + k, c = c0 + tx;
+        if (r < rows && c < cols) {
+            u64 v = src[vec + (size_t)r * cols + c];
+            if (tlo) {
+                const u64 e = (u64)r * c;
+                const u64 w = mulmod_b(tlo[e & (((u64)1 << lo_bits) - 1)], thi[e >> lo_bits], q, r0, r1);
+                v = mulmod_b(v < q ? v : barrett128(v, 0, q, r0, r1), w, q, r0, r1);
+            }
+            tile[k][tx] = v;
+        }
+    }
+    __syncthreads();
+    for (u32 k = ty; k < 32; k += 8) {
+        const u32 c = c0 + k, r = rr0 + tx;
+        if (r < rows && c < cols) dst[vec + (size_t)c * rows + r] = tile[tx][k];
+    }
+}
+
+hipError_t launch_transpose_tw(hipStream_t st, u64 *dst, const u64 *src, u32 rows, u32 cols, u32 n_vec, const ModConst &mc, const u64 *tlo, const u64 *thi,
+                               int lo_bits)
+{
+    if (!rows || !cols || !n_vec) return hipSuccess;
+    if (n_vec > 65535u) return hipErrorInvalidValue;
+    hipLaunchKernelGGL(k_transpose_tw, dim3((cols + 31) / 32, (rows + 31) / 32, n_vec), dim3(256), 0, st, dst, src, rows, cols, mc, tlo, thi, lo_bits);
+    return hipGetLastError();
+}
+
+// ---------------------------------------------------------------------------
 // Base conversion.  One lane = one coefficient; residues are read at stride N
 // (coalesced across lanes), mixed-radix digits stay in registers.
 // ---------------------------------------------------------------------------

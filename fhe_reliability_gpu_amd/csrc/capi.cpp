@@ -712,7 +712,8 @@ int fhe_fourstep_create(fhe_ctx *ctx, uint64_t n1, uint64_t n2, uint64_t mod, ui
 {
     if (!ctx || !out) return fail(FHE_ERR_INVALID, "null argument");
     const int l1 = ilog2_exact(n1), l2 = ilog2_exact(n2);
-    if (l1 < 1 || l2 < 1 || l1 + l2 > NTT_MAX_LOGN || mod < 2) return fail(FHE_ERR_INVALID, "n1 and n2 must be powers of two >= 2 with n1 * n2 <= 2^20");
+    if (l1 < 1 || l2 < 1 || l1 > NTT_MAX_LOGN || l2 > NTT_MAX_LOGN || l1 + l2 > 26 || mod < 2)
+        return fail(FHE_ERR_INVALID, "n1 and n2 must be powers of two, 2 <= n1, n2 <= 2^20, n1 * n2 <= 2^26");
     const u64 N = n1 * n2;
     if ((mod - 1) % N) return fail(FHE_ERR_INVALID, "N must divide mod - 1");
     if (mod >= ((u64)1 << 61)) return fail(FHE_ERR_UNSUPPORTED, "modulus must be below 2^61");
@@ -723,6 +724,32 @@ int fhe_fourstep_create(fhe_ctx *ctx, uint64_t n1, uint64_t n2, uint64_t mod, ui
     p->mod = mod;
     p->g = g % mod;
     p->log_n = l1 + l2;
+    p->log1 = l1;
+    p->log2 = l2;
+    if (p->log_n > NTT_MAX_LOGN) {
+        // past the largest single plan: the composition of four_step_ntt_prot.py:71-109 itself, each factor through the natural-order
+        // transform of its length; w^(k2 t1) from two tables of 2^lo_bits and 2^(log_n - lo_bits) entries
+        p->big = true;
+        p->lo_bits = (p->log_n + 1) / 2;
+        const u64 w = host::pow_mod(p->g, (mod - 1) / N, mod);
+        std::vector<u64> lo((size_t)1 << p->lo_bits), hi((size_t)1 << (p->log_n - p->lo_bits));
+        u64 cur = 1 % mod;
+        for (auto &x : lo) {
+            x = cur;
+            cur = host::mul_mod(cur, w, mod);
+        }
+        const u64 step = cur;           // w^(2^lo_bits)
+        cur = 1 % mod;
+        for (auto &x : hi) {
+            x = cur;
+            cur = host::mul_mod(cur, step, mod);
+        }
+        HIP_TRY(hipSetDevice(ctx->device));
+        HIP_TRY(p->tw_lo.upload(lo));
+        HIP_TRY(p->tw_hi.upload(hi));
+        *out = p.release();
+        return FHE_OK;
+    }
     if (ntt_gs_supported(p->log_n)) {
         int rc = cyclic_tables(ctx, p->log_n, mod, p->g, 0, 1 % mod, &p->t);
         if (rc) return rc;
@@ -748,6 +775,30 @@ int fhe_fourstep_ntt_batch(fhe_ctx *ctx, uint64_t *d_dst, const uint64_t *d_src,
     HIP_TRY(hipSetDevice(ctx->device));
     hipStream_t st = pick(ctx, stream);
     const size_t words = n_vec << p->log_n;
+    if (p->big) {
+        if (n_vec > 4096 || (n_vec << (p->log1 > p->log2 ? p->log1 : p->log2)) > ((size_t)1 << 24)) return fail(FHE_ERR_INVALID, "batch too large for the large-N four-step");
+        if (p->buf0.bytes < words * 8) {
+            HIP_TRY(hipStreamSynchronize(st));      // growing frees the old blocks
+            HIP_TRY(p->buf0.alloc(words * 8));
+            HIP_TRY(p->buf1.alloc(words * 8));
+        }
+        u64 *b0 = p->buf0.as<u64>(), *b1 = p->buf1.as<u64>();
+        const u32 n1 = (u32)p->n1, n2 = (u32)p->n2;
+        const ModConst mc = mod_const(p->mod);
+        hipError_t e;
+        int rc;
+        // A[t2][t1] = a[t1 + n1 t2] (:81)  ->  b0[t1][t2]
+        if ((e = launch_transpose_tw(st, b0, d_src, n2, n1, (u32)n_vec, mc, nullptr, nullptr, 0)) != hipSuccess) return hip_fail(e, "launch_transpose_tw");
+        // n1 transforms of length n2 along t2, natural order in and out (:84-90)
+        if ((rc = fhe_ntt_cyclic(ctx, b0, b1, p->log2, n_vec * n1, p->mod, p->g, 0, 0, st))) return rc;
+        // C[t1][k2] = B[t1][k2] w^(k2 t1) (:93) on the way to b1[k2][t1]
+        if ((e = launch_transpose_tw(st, b1, b0, n1, n2, (u32)n_vec, mc, p->tw_lo.as<u64>(), p->tw_hi.as<u64>(), p->lo_bits)) != hipSuccess) return hip_fail(e, "launch_transpose_tw");
+        // n2 transforms of length n1 along t1 (:96-102)
+        if ((rc = fhe_ntt_cyclic(ctx, b1, b0, p->log1, n_vec * n2, p->mod, p->g, 0, 0, st))) return rc;
+        // y[k1 n2 + k2] = Y[k2][k1] (:105-108)
+        if ((e = launch_transpose_tw(st, d_dst, b1, n2, n1, (u32)n_vec, mc, nullptr, nullptr, 0)) != hipSuccess) return hip_fail(e, "launch_transpose_tw");
+        return FHE_OK;
+    }
     const bool cut = p->t && sub_batch_polys(ctx, p->log_n, n_vec, 1) != 0;      // (then the hand-off goes through per-stream scratch)
     if (!cut && p->tmp.bytes < words * 8) {
         HIP_TRY(hipStreamSynchronize(st));      // growing frees the old block

@@ -211,6 +211,11 @@ struct fhe_fourstep {
     int log_n = 0;
     fhe_ntt_tables *t = nullptr;   // natural-order table set of length n1 * n2 (owned by the context's cache)
     DevBuf tmp;                    // hand-off buffer between the two launches, grown to the largest batch seen
+    // n1 * n2 past the largest single plan (2^21 .. 2^26): the reference's own composition -- transpose, n1 transforms of length n2,
+    // twiddle w^(k2 t1) on the way through the second transpose, n2 transforms of length n1, transpose
+    bool big = false;
+    int log1 = 0, log2 = 0, lo_bits = 0;
+    DevBuf tw_lo, tw_hi, buf0, buf1;
 };
 
 

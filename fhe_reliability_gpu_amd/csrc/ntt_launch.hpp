@@ -138,6 +138,9 @@ struct ModConst {
 // per unit of 2^logn words: dst[i] = src[bitrev(i)] (* scale mod q when do_scale).  dst != src.
 hipError_t launch_bitrev_scale(hipStream_t st, u64 *dst, const u64 *src, int logn, u32 units, const ModConst &mc, u64 scale,
                                bool do_scale);
+// per vector of rows x cols words: dst[c][r] = src[r][c] (* w^(r c) mod q when tlo != nullptr, w^e = tlo[e mod 2^lo_bits] * thi[e >> lo_bits])
+hipError_t launch_transpose_tw(hipStream_t st, u64 *dst, const u64 *src, u32 rows, u32 cols, u32 n_vec, const ModConst &mc, const u64 *tlo, const u64 *thi,
+                               int lo_bits);
 // out_h = (a_h - b_h) * scal[l] (+ add_h) mod q_l over `limbs` limbs from table index limb0, for one half
 // (out1 == nullptr) or both halves of a key switch in one launch; a_h = a + h * a_stride, b_h = b + h * b_stride (in words);
 // a == nullptr / b == nullptr: that operand is zero

@@ -149,11 +149,13 @@ int fhe_ntt_cyclic(fhe_ctx *ctx, uint64_t *d_data, uint64_t *d_scratch, int log_
 
 /* ---- four-step transform (a6) -------------------------------------------------- */
 /* four_step_ntt(a, N) of reliability_test/four_step_ntt_prot.py:71-109 with N = n1*n2
- * (both powers of two, n1 != n2 allowed, N <= 2^20): column transforms, twiddle w^(k2 t1), row
+ * (both powers of two, n1 != n2 allowed): column transforms, twiddle w^(k2 t1), row
  * transforms, transposed output; equals ntt_direct (:49-58).  g = generator (G=3, :17). */
-/* Range: n1 * n2 <= 2^20 and mod < 2^61 (FHE_ERR_INVALID / FHE_ERR_UNSUPPORTED beyond: the two-launch natural-order transform
- * covers the sizes the engine's tile plans cover; round 1's transpose / twiddle composition, which reached 2^26, is gone).
- * A plan's hand-off buffer is reused by every call on it: one plan, one stream at a time (see fhe_hmult). */
+/* Range: 2 <= n1, n2 <= 2^20, n1 * n2 <= 2^26, mod < 2^61 (FHE_ERR_INVALID / FHE_ERR_UNSUPPORTED beyond).  Up to N = 2^20 the whole flow
+ * is ONE natural-order transform of the engine (two launches, no transpose pass); from 2^21 to 2^26 (the reference's default modulus
+ * 998244353 admits N up to 2^23) it is the reference's composition itself: transpose, n1 transforms of length n2, the twiddle on the
+ * way through the second transpose, n2 transforms of length n1, transpose -- five sweeps, plan-owned buffers of two batches.
+ * A plan's hand-off buffers are reused by every call on it: one plan, one stream at a time (see fhe_hmult). */
 int fhe_fourstep_create(fhe_ctx *ctx, uint64_t n1, uint64_t n2, uint64_t mod, uint64_t g, fhe_fourstep **out);
 int fhe_fourstep_destroy(fhe_fourstep *p);
 int fhe_fourstep_ntt(fhe_ctx *ctx, uint64_t *d_dst, const uint64_t *d_src, fhe_fourstep *p, void *stream);
