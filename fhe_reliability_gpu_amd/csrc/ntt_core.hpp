@@ -550,7 +550,8 @@ struct RowPass {
     // coalesced copy HBM -> LDS (inverse, raw words): 2 points (16 bytes) per lane
     static FHE_D void copy_in(int tid, const u64 *__restrict__ base, elem *__restrict__ lds)
     {
-        // (unroll 8 -- all of a thread's loads in flight at once -- measured slower: 0.398 against 0.391 ms per 512 MiB inverse, twice)
+        // (unroll 8 -- all of a thread's loads in flight at once -- measured slower: 0.398 against 0.391 ms per 512 MiB inverse, and slower for
+        // the key switch's small INTT launches as well: 7.2 / 11.5 / 24.7 us against 6.4 / 10.9 / 23.4 at 16 / 256 / 704 workgroups)
 #pragma unroll 2
         for (int i = tid; i < TR * NPTS / 2; i += NTHREADS) {
             const u32 row = (u32)i / (NPTS / 2), g = ((u32)i % (NPTS / 2)) * 2;
