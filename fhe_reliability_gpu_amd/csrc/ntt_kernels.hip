@@ -265,7 +265,21 @@ static hipError_t launch_transform(hipStream_t st, const PassArgs &a, int which,
         if (e != hipSuccess || which == 0) return e;
         return launch_pass<typename PS::Row, LOGN, INV, false>(st, second);
     } else {
-        hipError_t e = which == 1 ? hipSuccess : launch_pass<typename PS::Row, LOGN, INV, false>(st, first);
+        hipError_t e = hipSuccess;
+        if (which != 1) {
+            bool done = false;
+            if constexpr (LOGN == 17 && GEO == 1) {
+                // a key switch's INTTs at 2^17 are launches of 500-1000 workgroups whose time is one workgroup's own chain of phases: with
+                // 8-row tiles a thread walks every phase twice (512 register sets for 256 threads); 4-row tiles make it once and put twice
+                // as many waves on a CU (opening INTT of 32 limbs: 32.5 -> 26.3 us; batches that fill the chip keep the 8-row tile)
+                typedef RowPass<A, typename PS::PL::Row, LOGN, 4, NTT_THREADS, true, IO_CANONICAL, IO_LAZY, PS::RED_FIRST, PS::SB> RowSmall;
+                if (a.units * PS::Row::TILES >= 768u && a.units * PS::Row::TILES <= 2048u) {     // (576 workgroups: 14.7 us either way, 15.7 with the small tile)
+                    e = launch_pass<RowSmall, LOGN, INV, false>(st, first);
+                    done = true;
+                }
+            }
+            if (!done) e = launch_pass<typename PS::Row, LOGN, INV, false>(st, first);
+        }
         if (e != hipSuccess || which == 0) return e;
         return launch_pass<typename PS::Col, LOGN, INV, true>(st, second);
     }
