@@ -192,7 +192,9 @@ struct fhe_keyswitch {
     // taken at launch time, so flipping it between launches is safe under the one-plan-one-caller rule)
     DevBuf acc2, conv2, hsp2, hdown_jobs2;
     int cur = 0;
-    u64 *acc_cur() const { return (cur ? acc2 : acc).as<u64>(); }
+    DevBuf acc_multi;                  // hoisted batches: the sums of up to four rotations formed in one pass over the shared digits ([4][2][MO][N])
+    u64 *acc_ovr = nullptr;            // != nullptr: the sums the mod-down in flight works on (one slot of acc_multi)
+    u64 *acc_cur() const { return acc_ovr ? acc_ovr : (cur ? acc2 : acc).as<u64>(); }
     u64 *conv_cur() const { return (cur ? conv2 : conv).as<u64>(); }
     u64 *hsp_cur() const { return (cur ? hsp2 : hsp).as<u64>(); }
     DevBuf hsp, hdown_rows, hdown_jobs; // hoisted rotations (allocated on first use): [2][K][N] special limbs of sigma(sums) in coefficient form, the mod-down jobs that read them

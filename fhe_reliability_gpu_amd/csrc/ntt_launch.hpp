@@ -218,6 +218,14 @@ struct KsMacArgs {
     u32 cn, clo, sp_shift;
 };
 hipError_t launch_ks_mac(hipStream_t st, const KsMacArgs &a);
+// n <= 4 keys on the same digits: acc[r] = sum_d ext_d * evk[r][d] (a.acc / a.evk unused)
+struct KsMacMultiArgs {
+    KsMacArgs a;
+    u32 n;
+    const u64 *evk[4];
+    u64 *acc[4];
+};
+hipError_t launch_ks_mac_multi(hipStream_t st, const KsMacMultiArgs &m);
 // The same inner product with the LAST pass of the extended limbs' forward transform fused in (ntt_kernels.hip k_ks_rowmac):
 // `ext` then holds what the transform's first launch left (the column pass's lazy words; for single-pass sizes the
 // base-extension output itself), one workgroup per (owned limb, row tile) runs the row pass of every digit's limb in LDS,

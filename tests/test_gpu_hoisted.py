@@ -246,14 +246,16 @@ def test_bsgs_matvec_on_a_trivial_ciphertext_is_the_plaintext_formula(F, eng):
     eng.check()
 
 
-def test_hoisted_rotations_one_stream_two_streams_and_capture_agree(F, eng):
+@pytest.mark.parametrize("logn,L,K,dnum,n_rot,bits", [(13, 4, 2, 2, 5, 50), (12, 3, 2, 3, 9, 61), (14, 5, 1, 5, 2, 50)])
+def test_hoisted_rotations_one_stream_two_streams_and_capture_agree(F, eng, logn, L, K, dnum, n_rot, bits):
     """fhe_rotate_hoisted alternates its rotations between the caller's stream and the context's side stream (second buffer set);
-    with the side stream switched off ("ntt_split" 0) and inside a stream capture (where it must not fork) the words are the same."""
+    with the side stream switched off ("ntt_split" 0) and inside a stream capture (where it must not fork) the words are the same.
+    On one stream the inner products of up to four rotations are formed in one pass over the shared digits (launch_ks_mac_multi):
+    batches of 5 and 9 cross the group boundary, the 61-bit shape takes the integer path."""
     import torch
     from fhe_reliability_gpu_amd._lib import check, lib
-    logn, L, K, dnum, n_rot = 13, 4, 2, 2, 5
     n = 1 << logn
-    qk = F.create_moduli(n, [50] * (L + K))
+    qk = F.create_moduli(n, [bits] * (L + K))
     tk = eng.tables(logn, qk)
     ks = F.KeySwitch(eng, tk, L, K, dnum)
     g = torch.Generator(device="cuda")
