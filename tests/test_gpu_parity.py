@@ -64,7 +64,11 @@ def test_forward_inverse_match_oracle(F, eng, O, logn, bits, mode):
     rps = [O.root_powers(q, logn) for q in qs]
     rng = np.random.default_rng(1000 * logn + bits)
     data = _rand_limbs(rng, qs, N, n_poly)
-    data[0, 0, :] = qs[0] - 1                            # extreme values for the lazy ranges
+    data[0, 0, :] = qs[0] - 1                            # extreme values for the lazy ranges: the all-sums register doubles at every stage
+    if limbs >= 2:
+        data[0, 1, 0::2], data[0, 1, 1::2] = qs[1] - 1, 0                              # ... and the difference branches carry q - 1
+    if n_poly >= 2:
+        data[1, 0, :] = rng.integers(0, 2, N, dtype=np.uint64) * np.uint64(qs[0] - 1)   # random corners of [0, q)^N
     d = eng.upload(data)
     t.forward(d, n_poly=n_poly)
     fwd = d.download()
