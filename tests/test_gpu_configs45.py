@@ -460,3 +460,29 @@ def test_fourstep_past_the_largest_plan_matches_oracle(F, eng, n1, n2, n_vec, mo
     # test_four_step_batch_and_cyclic_round_trip makes; the four-step restatement itself is pinned against it at small sizes in tests/)
     for v in range(n_vec):
         assert (got[v] == O.ntt_cyclic(a[v], mod, g)).all(), v
+
+
+def test_round3_entry_points_report_misuse(F, eng):
+    """Statuses, not crashes: the sharded one-transform hmult phases on a plan without gather buffers, on a shape that rescales in a
+    separate step, with null outputs; the option switch; an oversized batch of the large-N four-step."""
+    import ctypes as C
+    from fhe_reliability_gpu_amd._lib import lib
+    N = 1 << 13
+    qs = F.create_moduli(N, [50] * 6)
+    t = eng.tables(13, qs)
+    ks = F.KeySwitch(eng, t, 4, 2, 2)
+    assert lib.fhe_hmult_shard_fusable(eng._h, ks._h) == 0                                   # one-device plan: fhe_hmult does it itself
+    assert lib.fhe_hmult_shard_finish_begin(eng._h, ks._h, None, None, None) != 0
+    assert lib.fhe_hmult_shard_finish_end(eng._h, ks._h, None, None, None, None, None) != 0
+    assert lib.fhe_hmult_shard_fusable(None, None) == 0
+    with pytest.raises(Exception):
+        eng.set_option("no_such_option", 1)
+    eng.set_option("hmult_fused_rescale", 1)
+    h = C.c_void_p()
+    assert lib.fhe_fourstep_create(eng._h, 1 << 11, 1 << 10, 998244353, 3, C.byref(h)) == 0
+    try:
+        buf = eng.alloc(1 << 21)
+        assert lib.fhe_fourstep_ntt_batch(eng._h, buf.ptr, buf.ptr, h, 1 << 14, None) != 0       # 2^14 vectors of 2^21 words: refused before any launch
+        assert lib.fhe_fourstep_ntt_batch(eng._h, buf.ptr, buf.ptr, h, 0, None) == 0             # empty batch
+    finally:
+        lib.fhe_fourstep_destroy(h)
