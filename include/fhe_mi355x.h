@@ -68,7 +68,9 @@ int fhe_ctx_stream(fhe_ctx *ctx, void **stream_out);
  * loads / stores on the external side of the two launches (always / never / for sub-batched calls: the default); "ntt_pingpong" 1 / 0 / -1 = the two launches hand
  * over through a per-stream scratch buffer of one sub-batch, so that both run out of place (always / never / for calls that are
  * sub-batched: the default); "ks_fused" -1 / 0 / 1 = key-switch inner product
- * fused with the extended limbs' row pass by shape / never / always;
+ * fused with the extended limbs' row pass by shape / never / always (hoisted batches of two or more elements transform the shared digits
+ * once and use the plain inner product unless this is set); "hmult_fused_rescale" 1 (default) / 0 = fhe_hmult with rescale runs the mod-down and
+ * the rescale behind one forward transform where the shape allows (two-launch sizes, K >= 2, no plain modulus) / as two steps (FHE_HMULT_FUSED_RESCALE);
  * "tile_geo" column-tile geometry of the two-launch path; "ntt_only_pass" 0 / 1 = launch only the
  * first / second pass of a two-pass size (timing of the individual kernels; -1 = whole transform).  Environment overrides at context creation: FHE_NTT_MODE=twopass|fused,
  * FHE_FUSED_DIST, FHE_FUSED_WGS.  Results are identical in every setting. */
