@@ -98,7 +98,7 @@ def _ks_worker(rank, world, port, logn, L, K, dnum, out_dir):
         dist.destroy_process_group()
 
 
-@pytest.mark.parametrize("world,L,K,dnum", [(2, 4, 2, 2), (3, 5, 2, 3), (2, 3, 1, 3), (3, 2, 4, 1)])
+@pytest.mark.parametrize("world,L,K,dnum", [(2, 4, 2, 2), (3, 5, 2, 3), (2, 3, 1, 3), (3, 2, 4, 1), (8, 10, 4, 5)])   # (8 ranks: the driver's largest launch; four of them own no special limb)
 def test_sharded_keyswitch_gloo(tmp_path, world, L, K, dnum):
     """Limbs sharded over ranks, in-place all-gathers at the two base-conversion joins: the concatenated per-rank results equal
     the single-device key switch (oracle/keyswitch_ref.py, the composite the GPU tests pin fhe_keyswitch_apply to).  Covers
@@ -186,7 +186,7 @@ def _hm_worker(rank, world, port, logn, L, K, dnum, out_dir, fused=True):
         dist.destroy_process_group()
 
 
-@pytest.mark.parametrize("world,L,K,dnum,fused", [(2, 4, 2, 2, True), (3, 5, 2, 3, True), (3, 3, 1, 3, True), (2, 4, 2, 2, False), (3, 5, 2, 3, False)])
+@pytest.mark.parametrize("world,L,K,dnum,fused", [(2, 4, 2, 2, True), (3, 5, 2, 3, True), (3, 3, 1, 3, True), (2, 4, 2, 2, False), (3, 5, 2, 3, False), (8, 9, 8, 3, True)])
 def test_sharded_hmult_gloo(tmp_path, world, L, K, dnum, fused):
     """BASELINE config 4's composite with the limbs sharded: tensor product on the owned rows, the sharded key switch with d0 / d1 as
     addends, the rescale with ONE broadcast of the last limbs -- concatenated per-rank results equal oracle hmult_ref.  Both flows of
