@@ -286,3 +286,125 @@ def test_sharded_hoisted_rotations_real_plan(tmp_path, world, logn, L, K, dnum, 
         assert (cat(2 * r) == w0).all() and (cat(2 * r + 1) == w1).all(), f"galois element {e}"
     v0, v1 = rotate_ref(c0, c1, elts[0], gk, qs, L, K, dnum, logn)
     assert (cat(6) == v0).all() and (cat(7) == v1).all()
+
+
+@pytest.mark.parametrize("world,logn,L,K,dnum,bits", [(8, 13, 10, 4, 5, 50), (8, 13, 9, 8, 3, 61), (6, 14, 7, 2, 7, 50)])
+def test_many_ranks_in_one_process_real_plan(world, logn, L, K, dnum, bits):
+    """The driver's largest launch has 8 ranks; a GPU box admits 6 processes.  Here EVERY rank's C-ABI plan (fhe_keyswitch_create_sharded with
+    world = 8 and rank = 0..7: row maps, gaps, ranks that own no special limb, ranks that own one ciphertext limb) runs in ONE process, the
+    three collectives replaced by the slot copies they amount to: a sharded rotation and a sharded multiply + relinearize + rescale (the flow with
+    the broadcast between the conversion and the last transform where the shape allows, and the separate-rescale flow) -- concatenated rows
+    against fhe_rotate / fhe_hmult on one device, word for word."""
+    import ctypes as C
+
+    import torch
+
+    import fhe_reliability_gpu_amd as F
+    from fhe_reliability_gpu_amd._lib import check, lib, vp
+    from fhe_reliability_gpu_amd.dist import ks_layout, own_ct_rows, own_rows
+    eng = F.Engine(0)
+    qs, c1, key, c0 = _case(logn, L, K, dnum, bits)
+    _, b0, _, b1 = _case(logn, L, K, dnum, bits, seed=5)
+    N = 1 << logn
+    t = eng.tables(logn, qs)
+    P = lambda x: C.c_void_p(x.data_ptr() if x is not None and x.numel() else 0)
+    lays = [ks_layout(L, K, world, r) for r in range(world)]
+    cmax, smax = lays[0]["cmax"], lays[0]["smax"]
+    zeros = lambda rows: torch.zeros((rows, N), dtype=torch.int64, device="cuda")
+    g1 = [zeros(world * cmax) for _ in range(world)]
+    g2 = [zeros(world * 2 * smax) for _ in range(world)]
+    bc = [zeros(3) for _ in range(world)]
+    plans = []
+    for r in range(world):
+        h = vp()
+        check(lib.fhe_keyswitch_create_sharded(eng._h, t._h, L, K, dnum, world, r, P(g1[r]), P(g2[r]), P(bc[r]), C.byref(h)))
+        plans.append(h)
+    owner = next(r for r, l in enumerate(lays) if l["clo"] <= L - 1 < l["clo"] + l["cn"])
+    loc = lambda a, r: _to_cuda(a[own_ct_rows(lays[r])])
+    keyl = [_to_cuda(key[:, :, own_rows(lays[r])]) for r in range(world)]
+
+    def gather(bufs, rows):
+        torch.cuda.synchronize()
+        for r in range(world):
+            for s in range(world):
+                if r != s:
+                    bufs[r][s * rows:(s + 1) * rows] = bufs[s][s * rows:(s + 1) * rows]
+        torch.cuda.synchronize()
+
+    def bcast(n_rows):
+        torch.cuda.synchronize()
+        for r in range(world):
+            if r != owner:
+                bc[r][:n_rows] = bc[owner][:n_rows]
+        torch.cuda.synchronize()
+
+    try:
+        # ---- rotation
+        g = 5
+        c0l, c1l = [loc(c0, r) for r in range(world)], [loc(c1, r) for r in range(world)]
+        for r in range(world):
+            check(lib.fhe_rotate_shard_begin(eng._h, plans[r], P(c1l[r]), g, None))
+        gather(g1, cmax)
+        for r in range(world):
+            check(lib.fhe_rotate_shard_inner(eng._h, plans[r], P(keyl[r]), None))
+        gather(g2, 2 * smax)
+        rot = []
+        for r in range(world):
+            o0, o1 = zeros(lays[r]["cn"]), zeros(lays[r]["cn"])
+            check(lib.fhe_rotate_shard_finish(eng._h, plans[r], P(o0), P(o1), P(c0l[r]), g, None))
+            rot.append((o0, o1))
+        eng.sync()
+        ks = F.KeySwitch(eng, t, L, K, dnum)
+        w0, w1 = ks.rotate(eng.upload(c0), eng.upload(c1), g, eng.upload(key))
+        assert (np.concatenate([_from_cuda(o[0]) for o in rot]) == w0.download()).all()
+        assert (np.concatenate([_from_cuda(o[1]) for o in rot]) == w1.download()).all()
+        # ---- multiply + relinearize + rescale, both flows
+        h0, h1 = ks.hmult(eng.upload(c0), eng.upload(c1), eng.upload(b0), eng.upload(b1), eng.upload(key), rescale=True)
+        h0, h1 = h0.download(), h1.download()
+        rs_rows = [max(0, min(l["clo"] + l["cn"], L - 1) - l["clo"]) for l in lays]
+        fusable = bool(lib.fhe_hmult_shard_fusable(eng._h, plans[0]))
+        assert fusable == (logn >= 13 and K >= 2)
+        for fused in ([True, False] if fusable else [False]):
+            eng.set_option("hmult_fused_rescale", 1 if fused else 0)
+            d = []
+            for r in range(world):
+                a0, a1, x0, x1 = loc(c0, r), loc(c1, r), loc(b0, r), loc(b1, r)
+                dd = [torch.zeros_like(a0) for _ in range(3)]
+                if lays[r]["cn"]:
+                    check(lib.fhe_tensor_product(eng._h, P(dd[0]), P(dd[1]), P(dd[2]), P(a0), P(a1), P(x0), P(x1), t._h, lays[r]["cn"], lays[r]["clo"], None))
+                d.append(dd)
+            for r in range(world):
+                check(lib.fhe_keyswitch_shard_begin(eng._h, plans[r], P(d[r][2]), None))
+            gather(g1, cmax)
+            for r in range(world):
+                check(lib.fhe_keyswitch_shard_inner(eng._h, plans[r], P(d[r][2]), P(keyl[r]), None))
+            gather(g2, 2 * smax)
+            outs = []
+            if fused:
+                for r in range(world):
+                    check(lib.fhe_hmult_shard_finish_begin(eng._h, plans[r], P(d[r][0]), P(d[r][1]), None))
+                bcast(2)
+                for r in range(world):
+                    o = torch.zeros((2, rs_rows[r], N), dtype=torch.int64, device="cuda")
+                    check(lib.fhe_hmult_shard_finish_end(eng._h, plans[r], P(o[0]), P(o[1]), P(d[r][0]), P(d[r][1]), None))
+                    outs.append(o)
+            else:
+                mid = []
+                for r in range(world):
+                    m = torch.zeros((2, lays[r]["cn"], N), dtype=torch.int64, device="cuda")
+                    check(lib.fhe_keyswitch_shard_finish(eng._h, plans[r], P(m[0]), P(m[1]), P(d[r][0]), P(d[r][1]), None))
+                    mid.append(m)
+                for r in range(world):
+                    check(lib.fhe_rescale_shard_begin(eng._h, plans[r], P(mid[r]), 2, None))
+                bcast(2)
+                for r in range(world):
+                    o = torch.zeros((2, rs_rows[r], N), dtype=torch.int64, device="cuda")
+                    check(lib.fhe_rescale_shard_finish(eng._h, plans[r], P(o), P(mid[r]), 2, None))
+                    outs.append(o)
+            eng.sync()
+            assert (np.concatenate([_from_cuda(o[0]) for o in outs]) == h0).all(), fused
+            assert (np.concatenate([_from_cuda(o[1]) for o in outs]) == h1).all(), fused
+    finally:
+        eng.set_option("hmult_fused_rescale", 1)
+        for h in plans:
+            lib.fhe_keyswitch_destroy(h)
