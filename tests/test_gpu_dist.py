@@ -292,7 +292,7 @@ def test_sharded_hoisted_rotations_real_plan(tmp_path, world, logn, L, K, dnum, 
 def test_many_ranks_in_one_process_real_plan(world, logn, L, K, dnum, bits):
     """The driver's largest launch has 8 ranks; a GPU box admits 6 processes.  Here EVERY rank's C-ABI plan (fhe_keyswitch_create_sharded with
     world = 8 and rank = 0..7: row maps, gaps, ranks that own no special limb, ranks that own one ciphertext limb) runs in ONE process, the
-    three collectives replaced by the slot copies they amount to: a sharded rotation and a sharded multiply + relinearize + rescale (the flow with
+    three collectives replaced by the slot copies they amount to: a sharded rotation, three hoisted rotations and a sharded multiply + relinearize + rescale (the flow with
     the broadcast between the conversion and the last transform where the shape allows, and the separate-rescale flow) -- concatenated rows
     against fhe_rotate / fhe_hmult on one device, word for word."""
     import ctypes as C
@@ -320,6 +320,10 @@ def test_many_ranks_in_one_process_real_plan(world, logn, L, K, dnum, bits):
         check(lib.fhe_keyswitch_create_sharded(eng._h, t._h, L, K, dnum, world, r, P(g1[r]), P(g2[r]), P(bc[r]), C.byref(h)))
         plans.append(h)
     owner = next(r for r, l in enumerate(lays) if l["clo"] <= L - 1 < l["clo"] + l["cn"])
+    # (the library's launches run on the engine's own non-blocking stream, torch's fills on torch's: outputs are torch.empty, and the
+    # buffers that were zero-filled are settled before the first launch)
+    empty = lambda *shape: torch.empty(shape, dtype=torch.int64, device="cuda")
+    torch.cuda.synchronize()
     loc = lambda a, r: _to_cuda(a[own_ct_rows(lays[r])])
     keyl = [_to_cuda(key[:, :, own_rows(lays[r])]) for r in range(world)]
 
@@ -350,7 +354,7 @@ def test_many_ranks_in_one_process_real_plan(world, logn, L, K, dnum, bits):
         gather(g2, 2 * smax)
         rot = []
         for r in range(world):
-            o0, o1 = zeros(lays[r]["cn"]), zeros(lays[r]["cn"])
+            o0, o1 = empty(lays[r]["cn"], N), empty(lays[r]["cn"], N)
             check(lib.fhe_rotate_shard_finish(eng._h, plans[r], P(o0), P(o1), P(c0l[r]), g, None))
             rot.append((o0, o1))
         eng.sync()
@@ -358,6 +362,35 @@ def test_many_ranks_in_one_process_real_plan(world, logn, L, K, dnum, bits):
         w0, w1 = ks.rotate(eng.upload(c0), eng.upload(c1), g, eng.upload(key))
         assert (np.concatenate([_from_cuda(o[0]) for o in rot]) == w0.download()).all()
         assert (np.concatenate([_from_cuda(o[1]) for o in rot]) == w1.download()).all()
+        # ---- hoisted rotations: ONE gather of the input for all elements, one gather of the special limbs per element
+        elts = [3, 2 * N - 1, 9]
+        pk_full = [ks.prepare_galois_key(eng.upload(key), e) for e in elts]
+        want = ks.rotate_hoisted(eng.upload(c0), eng.upload(c1), elts, pk_full)
+        pkl = []
+        for r in range(world):
+            per = []
+            for e in elts:
+                o = torch.empty_like(keyl[r])
+                check(lib.fhe_galois_key_prepare(eng._h, plans[r], P(o), P(keyl[r]), e, None))
+                per.append(o)
+            pkl.append(per)
+        for r in range(world):
+            check(lib.fhe_rotate_hoisted_shard_begin(eng._h, plans[r], P(c1l[r]), None))
+        gather(g1, cmax)
+        for r in range(world):
+            check(lib.fhe_rotate_hoisted_shard_extend(eng._h, plans[r], None))
+        for i, e in enumerate(elts):
+            for r in range(world):
+                check(lib.fhe_rotate_hoisted_shard_inner(eng._h, plans[r], P(c1l[r]), P(pkl[r][i]), e, None))
+            gather(g2, 2 * smax)
+            hz = []
+            for r in range(world):
+                o = empty(2, lays[r]["cn"], N)
+                check(lib.fhe_rotate_hoisted_shard_finish(eng._h, plans[r], P(o[0]), P(o[1]), P(c0l[r]), e, None))
+                hz.append(o)
+            eng.sync()
+            assert (np.concatenate([_from_cuda(o[0]) for o in hz]) == want[i][0].download()).all(), e
+            assert (np.concatenate([_from_cuda(o[1]) for o in hz]) == want[i][1].download()).all(), e
         # ---- multiply + relinearize + rescale, both flows
         h0, h1 = ks.hmult(eng.upload(c0), eng.upload(c1), eng.upload(b0), eng.upload(b1), eng.upload(key), rescale=True)
         h0, h1 = h0.download(), h1.download()
@@ -369,7 +402,7 @@ def test_many_ranks_in_one_process_real_plan(world, logn, L, K, dnum, bits):
             d = []
             for r in range(world):
                 a0, a1, x0, x1 = loc(c0, r), loc(c1, r), loc(b0, r), loc(b1, r)
-                dd = [torch.zeros_like(a0) for _ in range(3)]
+                dd = [torch.empty_like(a0) for _ in range(3)]
                 if lays[r]["cn"]:
                     check(lib.fhe_tensor_product(eng._h, P(dd[0]), P(dd[1]), P(dd[2]), P(a0), P(a1), P(x0), P(x1), t._h, lays[r]["cn"], lays[r]["clo"], None))
                 d.append(dd)
@@ -385,20 +418,20 @@ def test_many_ranks_in_one_process_real_plan(world, logn, L, K, dnum, bits):
                     check(lib.fhe_hmult_shard_finish_begin(eng._h, plans[r], P(d[r][0]), P(d[r][1]), None))
                 bcast(2)
                 for r in range(world):
-                    o = torch.zeros((2, rs_rows[r], N), dtype=torch.int64, device="cuda")
+                    o = empty(2, rs_rows[r], N)
                     check(lib.fhe_hmult_shard_finish_end(eng._h, plans[r], P(o[0]), P(o[1]), P(d[r][0]), P(d[r][1]), None))
                     outs.append(o)
             else:
                 mid = []
                 for r in range(world):
-                    m = torch.zeros((2, lays[r]["cn"], N), dtype=torch.int64, device="cuda")
+                    m = empty(2, lays[r]["cn"], N)
                     check(lib.fhe_keyswitch_shard_finish(eng._h, plans[r], P(m[0]), P(m[1]), P(d[r][0]), P(d[r][1]), None))
                     mid.append(m)
                 for r in range(world):
                     check(lib.fhe_rescale_shard_begin(eng._h, plans[r], P(mid[r]), 2, None))
                 bcast(2)
                 for r in range(world):
-                    o = torch.zeros((2, rs_rows[r], N), dtype=torch.int64, device="cuda")
+                    o = empty(2, rs_rows[r], N)
                     check(lib.fhe_rescale_shard_finish(eng._h, plans[r], P(o), P(mid[r]), 2, None))
                     outs.append(o)
             eng.sync()
