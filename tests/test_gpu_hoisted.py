@@ -275,6 +275,7 @@ def test_hoisted_rotations_one_stream_two_streams_and_capture_agree(F, eng, logn
         check(lib.fhe_rotate_hoisted(eng._h, ks._h, a0, a1, P(c0), P(c1), ge, kk, n_rot, C.c_void_p(s.cuda_stream)))
 
     s = torch.cuda.Stream()
+    torch.cuda.synchronize()          # operands and zero-filled outputs settled before the first call on another stream
     call(s)
     torch.cuda.synchronize()
     want = [(x.clone(), y.clone()) for x, y in zip(o0, o1)]
@@ -282,6 +283,7 @@ def test_hoisted_rotations_one_stream_two_streams_and_capture_agree(F, eng, logn
     try:
         for x in o0 + o1:
             x.zero_()
+        torch.cuda.synchronize()      # (the fills run on torch's default stream, the call on another one)
         call(s)
         torch.cuda.synchronize()
         assert all(bool((x == w[0]).all()) and bool((y == w[1]).all()) for x, y, w in zip(o0, o1, want))
@@ -292,6 +294,7 @@ def test_hoisted_rotations_one_stream_two_streams_and_capture_agree(F, eng, logn
         call(cap)
     for x in o0 + o1:
         x.zero_()
+    torch.cuda.synchronize()
     graph.replay()
     torch.cuda.synchronize()
     assert all(bool((x == w[0]).all()) and bool((y == w[1]).all()) for x, y, w in zip(o0, o1, want))
